@@ -1,0 +1,89 @@
+/*
+ * mi355_whisper.h — entry points of libmi355_whisper.so beyond the whisper.h-compatible set.
+ *
+ * These have no counterpart in whisper.h; they exist for (a) choosing the arithmetic mode at load
+ * time, (b) the stage-level parity tests (each stage of the path that whisper_full runs as one call at
+ * /root/reference/src/whisper-utils/whisper-processing.cpp:218-219 can be run and read back on its own)
+ * and (c) measurement.  All pointers are plain host pointers unless a name says `_device`.
+ * Every function returns 0 on success and a negative code on failure; none throws.
+ */
+#ifndef MI355_WHISPER_H
+#define MI355_WHISPER_H
+
+#include "whisper.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum mw_precision {
+    MW_PRECISION_BF16 = 0, /* bf16 weights / MFMA operands / KV caches, fp32 accumulate + residual stream */
+    MW_PRECISION_FP32 = 1  /* exact fp32 everywhere (f32 MFMA): the bit-exact-token mode for tiny/base */
+};
+
+/* Same as whisper_init_from_file_with_params (whisper-processing.cpp:112) with the arithmetic mode made
+   explicit.  whisper_init_* use MW_PRECISION_BF16 unless the environment variable
+   MI355_WHISPER_PRECISION is "fp32". */
+struct whisper_context *mw_init_from_file(const char *path_model, int gpu_device, int precision);
+struct whisper_context *mw_init_from_buffer(const void *buffer, size_t size, int gpu_device, int precision);
+
+/* model facts: n_vocab,n_audio_ctx,n_audio_state,n_audio_head,n_audio_layer,n_text_ctx,n_text_state,
+   n_text_head,n_text_layer,n_mels,ftype */
+int mw_hparams(struct whisper_context *ctx, int32_t out[11]);
+
+/* ---- stage-level entry points (same stages whisper_full chains) ---- */
+/* log-mel of host PCM; result stays in HBM */
+int mw_pcm_to_mel(struct whisper_context *ctx, const float *samples, int n_samples);
+/* same, PCM already resident in HBM (the timed region of bench.py starts here) */
+int mw_pcm_to_mel_device(struct whisper_context *ctx, const float *samples_device, int n_samples);
+int mw_mel_n_len(struct whisper_context *ctx);
+/* out[n_mel][n_len] (whisper.cpp layout) */
+int mw_get_mel(struct whisper_context *ctx, float *out);
+/* encoder + cross-K/V for the 30 s window starting at mel frame `seek` */
+int mw_encode(struct whisper_context *ctx, int seek, int audio_ctx);
+/* out[n_ctx][n_audio_state] fp32 */
+int mw_get_encoder_out(struct whisper_context *ctx, float *out);
+/* out[n_ctx][n_text_state] fp32: cross-attention keys (pre-scaled by dh^-1/4) or values of one layer */
+int mw_get_cross_kv(struct whisper_context *ctx, int layer, int is_v, float *out);
+/* decode n tokens of sequence `seq` at positions n_past..n_past+n-1; keeps logits of the last
+   min(n, 32) tokens */
+int mw_decode(struct whisper_context *ctx, const whisper_token *tokens, int n, int n_past, int seq);
+/* out[rows][n_vocab]; rows = min(n, 32) of the last mw_decode */
+int mw_get_logits(struct whisper_context *ctx, float *out);
+/* forget every cached key/value (start of a new prompt) */
+int mw_kv_clear(struct whisper_context *ctx);
+/* logits rules + sampler on one caller-supplied logits row (whisper_process_logits + samplers).
+   history: tokens sampled so far.  n_draws = 0: greedy arg-max, else inverse-CDF draws with u[].
+   Any of the three [n_vocab] outputs may be null.  tok_out gets max(1, n_draws) records. */
+int mw_process_logits(struct whisper_context *ctx, const struct whisper_full_params *params, float temperature,
+                      const float *logits_in, const whisper_token *history, int n_history, int has_ts, int seek_delta,
+                      int n_draws, const double *u, float *logits_out, float *logprobs_out, float *probs_out,
+                      whisper_token_data *tok_out);
+
+/* ---- measurement ---- */
+struct mw_timings {
+    double mel_ms, encode_ms, decode_ms, sample_ms, total_ms; /* host wall clock, cumulative */
+    int n_encode, n_decode, n_sample;
+};
+int mw_get_timings(struct whisper_context *ctx, struct mw_timings *out);
+int mw_reset_timings(struct whisper_context *ctx);
+/* the HIP stream every kernel of this context is launched on (for HIP-event timing by the caller) */
+void *mw_stream(struct whisper_context *ctx);
+int mw_synchronize(struct whisper_context *ctx);
+/* Benchmark-only: with n > 0, EOT is suppressed and no decoder may complete before n sampled tokens
+   (synthetic random weights otherwise end a window after a handful of tokens).  0 restores normal
+   behaviour.  See DESIGN.md "forced decode length". */
+int mw_set_force_decode_steps(struct whisper_context *ctx, int n);
+/* micro-benchmarks of single kernels on device-resident synthetic operands (bench.py roofline legs):
+   run `iters` launches of the decode step's weight-streaming projections for `rows` activation rows and
+   return the average milliseconds per launch measured with HIP events on the context's stream. */
+int mw_bench_decode_step(struct whisper_context *ctx, int rows, int n_past, int iters, float *ms_per_step);
+int mw_bench_mel(struct whisper_context *ctx, int n_samples, int iters, float *ms_per_call);
+int mw_bench_encode(struct whisper_context *ctx, int iters, float *ms_per_call);
+
+const char *mw_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

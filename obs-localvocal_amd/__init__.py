@@ -1,0 +1,396 @@
+"""obs-localvocal_amd — thin ctypes binding of libmi355_whisper.so (the C ABI in include/*.h).
+
+The product is the shared library; this module only declares its entry points for Python callers
+(tests, bench.py, __graft_entry__.py).  It contains no arithmetic and no fallback: if the library is
+missing or no MI355X is usable, loading a model raises.
+
+The directory name carries a hyphen (repo contract), so import it through `load_package()` in
+tests/conftest.py or `importlib` (see __graft_entry__.py); the module registers itself as
+`obs_localvocal_amd`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmi355_whisper.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+PRECISION_BF16 = 0
+PRECISION_FP32 = 1
+SAMPLING_GREEDY = 0
+SAMPLING_BEAM_SEARCH = 1
+
+
+class TokenData(C.Structure):  # whisper_token_data
+    _fields_ = [("id", C.c_int32), ("tid", C.c_int32), ("p", C.c_float), ("plog", C.c_float),
+                ("pt", C.c_float), ("ptsum", C.c_float), ("t0", C.c_int64), ("t1", C.c_int64),
+                ("t_dtw", C.c_int64), ("vlen", C.c_float)]
+
+
+class _Greedy(C.Structure):
+    _fields_ = [("best_of", C.c_int)]
+
+
+class _Beam(C.Structure):
+    _fields_ = [("beam_size", C.c_int), ("patience", C.c_float)]
+
+
+class FullParams(C.Structure):  # whisper_full_params (include/whisper.h)
+    _fields_ = [
+        ("strategy", C.c_int), ("n_threads", C.c_int), ("n_max_text_ctx", C.c_int), ("offset_ms", C.c_int),
+        ("duration_ms", C.c_int),
+        ("translate", C.c_bool), ("no_context", C.c_bool), ("no_timestamps", C.c_bool), ("single_segment", C.c_bool),
+        ("print_special", C.c_bool), ("print_progress", C.c_bool), ("print_realtime", C.c_bool),
+        ("print_timestamps", C.c_bool),
+        ("token_timestamps", C.c_bool), ("thold_pt", C.c_float), ("thold_ptsum", C.c_float), ("max_len", C.c_int),
+        ("split_on_word", C.c_bool), ("max_tokens", C.c_int),
+        ("speed_up", C.c_bool), ("debug_mode", C.c_bool), ("audio_ctx", C.c_int),
+        ("tdrz_enable", C.c_bool),
+        ("suppress_regex", C.c_char_p), ("initial_prompt", C.c_char_p),
+        ("prompt_tokens", C.POINTER(C.c_int32)), ("prompt_n_tokens", C.c_int),
+        ("language", C.c_char_p), ("detect_language", C.c_bool),
+        ("suppress_blank", C.c_bool), ("suppress_non_speech_tokens", C.c_bool),
+        ("temperature", C.c_float), ("max_initial_ts", C.c_float), ("length_penalty", C.c_float),
+        ("temperature_inc", C.c_float), ("entropy_thold", C.c_float), ("logprob_thold", C.c_float),
+        ("no_speech_thold", C.c_float),
+        ("greedy", _Greedy), ("beam_search", _Beam),
+        ("new_segment_callback", C.c_void_p), ("new_segment_callback_user_data", C.c_void_p),
+        ("progress_callback", C.c_void_p), ("progress_callback_user_data", C.c_void_p),
+        ("encoder_begin_callback", C.c_void_p), ("encoder_begin_callback_user_data", C.c_void_p),
+        ("abort_callback", C.c_void_p), ("abort_callback_user_data", C.c_void_p),
+        ("logits_filter_callback", C.c_void_p), ("logits_filter_callback_user_data", C.c_void_p),
+        ("grammar_rules", C.c_void_p), ("n_grammar_rules", C.c_size_t), ("i_start_rule", C.c_size_t),
+        ("grammar_penalty", C.c_float),
+    ]
+
+
+class ContextParams(C.Structure):  # whisper_context_params
+    _fields_ = [("use_gpu", C.c_bool), ("flash_attn", C.c_bool), ("gpu_device", C.c_int),
+                ("dtw_token_timestamps", C.c_bool), ("dtw_aheads_preset", C.c_int), ("dtw_n_top", C.c_int),
+                ("dtw_aheads_n_heads", C.c_size_t), ("dtw_aheads_heads", C.c_void_p), ("dtw_mem_size", C.c_size_t)]
+
+
+class Timings(C.Structure):
+    _fields_ = [("mel_ms", C.c_double), ("encode_ms", C.c_double), ("decode_ms", C.c_double),
+                ("sample_ms", C.c_double), ("total_ms", C.c_double), ("n_encode", C.c_int), ("n_decode", C.c_int),
+                ("n_sample", C.c_int)]
+
+
+class LvDetection(C.Structure):
+    _fields_ = [("result", C.c_int), ("text", C.c_char_p), ("start_timestamp_ms", C.c_uint64),
+                ("end_timestamp_ms", C.c_uint64), ("tokens", C.POINTER(TokenData)), ("n_tokens", C.c_int),
+                ("language", C.c_char_p)]
+
+
+# every symbol include/whisper.h, include/mi355_whisper.h and include/localvocal_hotpath.h declare
+EXPORTED_SYMBOLS = [
+    "whisper_log_set", "whisper_context_default_params", "whisper_context_default_params_by_ref",
+    "whisper_free_context_params", "whisper_init_from_file_with_params", "whisper_init_from_buffer_with_params",
+    "whisper_print_system_info", "whisper_free", "whisper_full_default_params", "whisper_full_default_params_by_ref",
+    "whisper_free_params", "whisper_full", "whisper_full_n_segments", "whisper_full_n_tokens",
+    "whisper_full_get_token_data", "whisper_token_to_str", "whisper_lang_auto_detect", "whisper_lang_str",
+    "whisper_full_get_segment_t0", "whisper_full_get_segment_t1", "whisper_full_get_segment_text",
+    "whisper_full_get_token_id", "whisper_full_get_token_p", "whisper_full_lang_id", "whisper_lang_id",
+    "whisper_lang_max_id", "whisper_is_multilingual", "whisper_n_vocab", "whisper_n_text_ctx", "whisper_n_audio_ctx",
+    "whisper_n_len", "whisper_token_eot", "whisper_token_sot", "whisper_token_solm", "whisper_token_prev",
+    "whisper_token_nosp", "whisper_token_not", "whisper_token_beg", "whisper_token_lang", "whisper_token_translate",
+    "whisper_token_transcribe", "whisper_tokenize",
+    "mw_init_from_file", "mw_init_from_buffer", "mw_hparams", "mw_pcm_to_mel", "mw_pcm_to_mel_device", "mw_mel_n_len",
+    "mw_get_mel", "mw_encode", "mw_get_encoder_out", "mw_get_cross_kv", "mw_decode", "mw_get_logits", "mw_kv_clear",
+    "mw_process_logits", "mw_get_timings", "mw_reset_timings", "mw_stream", "mw_synchronize",
+    "mw_set_force_decode_steps", "mw_bench_decode_step", "mw_bench_mel", "mw_bench_encode", "mw_last_error",
+    "lv_filter_create", "lv_filter_destroy", "lv_filter_params", "lv_filter_set_language", "lv_filter_set_thresholds",
+    "lv_filter_set_context_sentences", "lv_filter_push_sentence", "lv_filter_set_gpu_device", "lv_filter_load_model",
+    "lv_filter_unload_model", "lv_filter_context", "lv_run_whisper_inference", "lv_to_timestamp",
+]
+
+
+def build(force: bool = False) -> str:
+    """Compile libmi355_whisper.so for gfx950 (hipcc cross-compiles; no GPU needed)."""
+    if force:
+        subprocess.check_call(["make", "-C", CSRC, "clean", "-s"])
+    subprocess.check_call(["make", "-C", CSRC, "-j8", "-s"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libmi355_whisper.so is not built (run __graft_entry__.build()); there is no fallback path")
+    L = C.CDLL(LIB_PATH)
+    P = C.c_void_p
+    FP = C.POINTER(C.c_float)
+    IP = C.POINTER(C.c_int32)
+    L.whisper_context_default_params.restype = ContextParams
+    L.whisper_init_from_file_with_params.restype = P
+    L.whisper_init_from_file_with_params.argtypes = [C.c_char_p, ContextParams]
+    L.whisper_init_from_buffer_with_params.restype = P
+    L.whisper_init_from_buffer_with_params.argtypes = [P, C.c_size_t, ContextParams]
+    L.whisper_print_system_info.restype = C.c_char_p
+    L.whisper_free.argtypes = [P]
+    L.whisper_full_default_params.restype = FullParams
+    L.whisper_full_default_params.argtypes = [C.c_int]
+    L.whisper_full.argtypes = [P, FullParams, FP, C.c_int]
+    L.whisper_full_n_segments.argtypes = [P]
+    L.whisper_full_n_tokens.argtypes = [P, C.c_int]
+    L.whisper_full_get_token_data.restype = TokenData
+    L.whisper_full_get_token_data.argtypes = [P, C.c_int, C.c_int]
+    L.whisper_token_to_str.restype = C.c_char_p
+    L.whisper_token_to_str.argtypes = [P, C.c_int]
+    L.whisper_lang_auto_detect.argtypes = [P, C.c_int, C.c_int, FP]
+    L.whisper_lang_str.restype = C.c_char_p
+    L.whisper_lang_str.argtypes = [C.c_int]
+    L.whisper_lang_id.argtypes = [C.c_char_p]
+    L.whisper_full_get_segment_t0.restype = C.c_int64
+    L.whisper_full_get_segment_t0.argtypes = [P, C.c_int]
+    L.whisper_full_get_segment_t1.restype = C.c_int64
+    L.whisper_full_get_segment_t1.argtypes = [P, C.c_int]
+    L.whisper_full_get_segment_text.restype = C.c_char_p
+    L.whisper_full_get_segment_text.argtypes = [P, C.c_int]
+    L.whisper_full_lang_id.argtypes = [P]
+    L.whisper_tokenize.argtypes = [P, C.c_char_p, IP, C.c_int]
+    for n in ("whisper_token_eot", "whisper_token_sot", "whisper_token_solm", "whisper_token_prev", "whisper_token_nosp",
+              "whisper_token_not", "whisper_token_beg", "whisper_token_translate", "whisper_token_transcribe",
+              "whisper_n_vocab", "whisper_n_text_ctx", "whisper_n_audio_ctx", "whisper_n_len", "whisper_is_multilingual"):
+        getattr(L, n).argtypes = [P]
+    L.whisper_token_lang.argtypes = [P, C.c_int]
+    L.mw_init_from_file.restype = P
+    L.mw_init_from_file.argtypes = [C.c_char_p, C.c_int, C.c_int]
+    L.mw_init_from_buffer.restype = P
+    L.mw_init_from_buffer.argtypes = [P, C.c_size_t, C.c_int, C.c_int]
+    L.mw_hparams.argtypes = [P, IP]
+    L.mw_pcm_to_mel.argtypes = [P, FP, C.c_int]
+    L.mw_pcm_to_mel_device.argtypes = [P, P, C.c_int]
+    L.mw_mel_n_len.argtypes = [P]
+    L.mw_get_mel.argtypes = [P, FP]
+    L.mw_encode.argtypes = [P, C.c_int, C.c_int]
+    L.mw_get_encoder_out.argtypes = [P, FP]
+    L.mw_get_cross_kv.argtypes = [P, C.c_int, C.c_int, FP]
+    L.mw_decode.argtypes = [P, IP, C.c_int, C.c_int, C.c_int]
+    L.mw_get_logits.argtypes = [P, FP]
+    L.mw_kv_clear.argtypes = [P]
+    L.mw_process_logits.argtypes = [P, C.POINTER(FullParams), C.c_float, FP, IP, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.POINTER(C.c_double), FP, FP, FP, C.POINTER(TokenData)]
+    L.mw_get_timings.argtypes = [P, C.POINTER(Timings)]
+    L.mw_reset_timings.argtypes = [P]
+    L.mw_stream.restype = P
+    L.mw_stream.argtypes = [P]
+    L.mw_synchronize.argtypes = [P]
+    L.mw_set_force_decode_steps.argtypes = [P, C.c_int]
+    L.mw_bench_decode_step.argtypes = [P, C.c_int, C.c_int, C.c_int, FP]
+    L.mw_bench_mel.argtypes = [P, C.c_int, C.c_int, FP]
+    L.mw_bench_encode.argtypes = [P, C.c_int, FP]
+    L.mw_last_error.restype = C.c_char_p
+    L.lv_filter_create.restype = P
+    L.lv_filter_destroy.argtypes = [P]
+    L.lv_filter_params.restype = C.POINTER(FullParams)
+    L.lv_filter_params.argtypes = [P]
+    L.lv_filter_set_language.argtypes = [P, C.c_char_p]
+    L.lv_filter_set_thresholds.argtypes = [P, C.c_float, C.c_float]
+    L.lv_filter_set_context_sentences.argtypes = [P, C.c_int]
+    L.lv_filter_push_sentence.argtypes = [P, C.c_char_p]
+    L.lv_filter_set_gpu_device.argtypes = [P, C.c_int, C.c_int]
+    L.lv_filter_load_model.argtypes = [P, C.c_char_p]
+    L.lv_filter_unload_model.argtypes = [P]
+    L.lv_filter_context.restype = P
+    L.lv_filter_context.argtypes = [P]
+    L.lv_run_whisper_inference.argtypes = [P, FP, C.c_size_t, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(LvDetection)]
+    L.lv_to_timestamp.argtypes = [C.c_uint64, C.c_char_p, C.c_size_t]
+    _lib = L
+    return L
+
+
+def _fp(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def last_error() -> str:
+    return (lib().mw_last_error() or b"").decode(errors="replace")
+
+
+class Engine:
+    """One whisper_context on one GPU."""
+
+    def __init__(self, model_path: str, precision: int = PRECISION_BF16, device: int = 0, ctx=None):
+        self.L = lib()
+        self._own = ctx is None
+        self.ctx = ctx if ctx is not None else self.L.mw_init_from_file(model_path.encode(), device, precision)
+        if not self.ctx:
+            raise RuntimeError("mi355_whisper: failed to create context: " + last_error())
+        hp = (C.c_int32 * 11)()
+        self.L.mw_hparams(self.ctx, hp)
+        (self.n_vocab, self.n_audio_ctx, self.n_audio_state, self.n_audio_head, self.n_audio_layer, self.n_text_ctx,
+         self.n_text_state, self.n_text_head, self.n_text_layer, self.n_mels, self.ftype) = list(hp)
+        self.eot = self.L.whisper_token_eot(self.ctx)
+        self.sot = self.L.whisper_token_sot(self.ctx)
+        self.beg = self.L.whisper_token_beg(self.ctx)
+        self._keep = []
+
+    def close(self):
+        if self.ctx and self._own:
+            self.L.whisper_free(self.ctx)
+        self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed ({rc}): {last_error()}")
+
+    # ---- params ----
+    def default_params(self, strategy: int = SAMPLING_GREEDY, **kw) -> FullParams:
+        p = self.L.whisper_full_default_params(strategy)
+        for k, v in kw.items():
+            if k == "best_of":
+                p.greedy.best_of = v
+            elif k == "beam_size":
+                p.beam_search.beam_size = v
+            else:
+                if isinstance(v, str):
+                    v = v.encode()
+                if isinstance(v, bytes):
+                    self._keep.append(v)
+                setattr(p, k, v)
+        return p
+
+    # ---- stages ----
+    def mel(self, pcm: np.ndarray) -> np.ndarray:
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        self._check(self.L.mw_pcm_to_mel(self.ctx, _fp(pcm), len(pcm)), "mw_pcm_to_mel")
+        out = np.empty((self.n_mels, self.L.mw_mel_n_len(self.ctx)), np.float32)
+        self._check(self.L.mw_get_mel(self.ctx, _fp(out)), "mw_get_mel")
+        return out
+
+    def encode(self, seek: int = 0, audio_ctx: int = 0) -> np.ndarray:
+        self._check(self.L.mw_encode(self.ctx, seek, audio_ctx), "mw_encode")
+        n_ctx = audio_ctx if audio_ctx > 0 else self.n_audio_ctx
+        out = np.empty((n_ctx, self.n_audio_state), np.float32)
+        self._check(self.L.mw_get_encoder_out(self.ctx, _fp(out)), "mw_get_encoder_out")
+        return out
+
+    def cross_kv(self, layer: int, is_v: bool, n_ctx: int | None = None) -> np.ndarray:
+        out = np.empty((n_ctx or self.n_audio_ctx, self.n_text_state), np.float32)
+        self._check(self.L.mw_get_cross_kv(self.ctx, layer, int(is_v), _fp(out)), "mw_get_cross_kv")
+        return out
+
+    def kv_clear(self):
+        self._check(self.L.mw_kv_clear(self.ctx), "mw_kv_clear")
+
+    def decode(self, tokens, n_past: int = 0, seq: int = 0) -> np.ndarray:
+        t = np.ascontiguousarray(tokens, dtype=np.int32)
+        self._check(self.L.mw_decode(self.ctx, t.ctypes.data_as(C.POINTER(C.c_int32)), len(t), n_past, seq), "mw_decode")
+        out = np.empty((min(len(t), 32), self.n_vocab), np.float32)
+        self._check(self.L.mw_get_logits(self.ctx, _fp(out)), "mw_get_logits")
+        return out
+
+    def process_logits(self, params: FullParams, logits, history, temperature=0.0, has_ts=False, seek_delta=3000,
+                       n_draws=0, u=None):
+        lg = np.ascontiguousarray(logits, dtype=np.float32)
+        h = np.ascontiguousarray(history, dtype=np.int32)
+        o1 = np.empty(self.n_vocab, np.float32)
+        o2 = np.empty_like(o1)
+        o3 = np.empty_like(o1)
+        toks = (TokenData * max(1, n_draws))()
+        uu = np.ascontiguousarray(u if u is not None else np.zeros(max(1, n_draws)), dtype=np.float64)
+        self._check(self.L.mw_process_logits(self.ctx, C.byref(params), float(temperature), _fp(lg),
+                                             h.ctypes.data_as(C.POINTER(C.c_int32)), len(h), int(has_ts), int(seek_delta),
+                                             n_draws, uu.ctypes.data_as(C.POINTER(C.c_double)), _fp(o1), _fp(o2), _fp(o3),
+                                             toks), "mw_process_logits")
+        return o1, o2, o3, [dict(id=t.id, tid=t.tid, p=t.p, plog=t.plog, pt=t.pt, ptsum=t.ptsum) for t in toks]
+
+    # ---- whisper_full ----
+    def full(self, params: FullParams, pcm: np.ndarray) -> int:
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        return self.L.whisper_full(self.ctx, params, _fp(pcm), len(pcm))
+
+    def segments(self):
+        out = []
+        for i in range(self.L.whisper_full_n_segments(self.ctx)):
+            toks = []
+            for j in range(self.L.whisper_full_n_tokens(self.ctx, i)):
+                td = self.L.whisper_full_get_token_data(self.ctx, i, j)
+                toks.append(dict(id=td.id, tid=td.tid, p=td.p, plog=td.plog, pt=td.pt, ptsum=td.ptsum))
+            out.append(dict(t0=self.L.whisper_full_get_segment_t0(self.ctx, i),
+                            t1=self.L.whisper_full_get_segment_t1(self.ctx, i),
+                            text=self.L.whisper_full_get_segment_text(self.ctx, i), tokens=toks))
+        return out
+
+    def token_ids(self):
+        return [t["id"] for s in self.segments() for t in s["tokens"]]
+
+    def token_to_str(self, i: int) -> bytes:
+        return self.L.whisper_token_to_str(self.ctx, i)
+
+    def lang_auto_detect(self, offset_ms: int = 0):
+        probs = np.zeros(100, np.float32)
+        return self.L.whisper_lang_auto_detect(self.ctx, offset_ms, 1, _fp(probs)), probs
+
+    def set_force_decode_steps(self, n: int):
+        self._check(self.L.mw_set_force_decode_steps(self.ctx, n), "mw_set_force_decode_steps")
+
+    def timings(self) -> Timings:
+        t = Timings()
+        self.L.mw_get_timings(self.ctx, C.byref(t))
+        return t
+
+    def reset_timings(self):
+        self.L.mw_reset_timings(self.ctx)
+
+
+class Filter:
+    """LocalVocal-side mirror (include/localvocal_hotpath.h): transcription_filter_data + run_whisper_inference."""
+
+    def __init__(self, device: int = 0, precision: int = -1):
+        self.L = lib()
+        self.f = self.L.lv_filter_create()
+        if not self.f:
+            raise RuntimeError("lv_filter_create failed")
+        self.L.lv_filter_set_gpu_device(self.f, device, precision)
+
+    def close(self):
+        if self.f:
+            self.L.lv_filter_destroy(self.f)
+            self.f = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def params(self) -> FullParams:
+        return self.L.lv_filter_params(self.f).contents
+
+    def load_model(self, path: str) -> int:
+        return self.L.lv_filter_load_model(self.f, path.encode())
+
+    def engine(self) -> Engine:
+        return Engine("", ctx=self.L.lv_filter_context(self.f))
+
+    def run_whisper_inference(self, pcm, t0=0, t1=0, vad_state=1):
+        out = LvDetection()
+        if pcm is None:
+            rc = self.L.lv_run_whisper_inference(self.f, None, 0, t0, t1, vad_state, C.byref(out))
+        else:
+            pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+            rc = self.L.lv_run_whisper_inference(self.f, _fp(pcm), len(pcm), t0, t1, vad_state, C.byref(out))
+        if rc != 0:
+            raise RuntimeError("lv_run_whisper_inference failed")
+        toks = [dict(id=out.tokens[i].id, p=out.tokens[i].p) for i in range(out.n_tokens)]
+        return dict(result=out.result, text=out.text or b"", start=out.start_timestamp_ms, end=out.end_timestamp_ms,
+                    tokens=toks, language=(out.language or b"").decode())

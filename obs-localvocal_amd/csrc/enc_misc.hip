@@ -1,0 +1,153 @@
+// enc_misc.hip — K3 LayerNorm, row softmax of the unfused attention path, small utility kernels.
+// HBM-bound streaming kernels: one wave per row, 16-byte loads, statistics by wave shuffles.
+// LayerNorm follows ggml_norm as whisper.cpp uses it (eps 1e-5, mean then centred variance;
+// SURVEY.md A.3), reached from whisper_full (/root/reference/src/whisper-utils/whisper-processing.cpp:218).
+#include "kernels.hpp"
+
+#include <hip/hip_bf16.h>
+
+namespace mw {
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ void store_out(float *p, float v) { *p = v; }
+__device__ __forceinline__ void store_out(bf16_t *p, float v) {
+    __hip_bfloat16 h = __float2bfloat16(v);
+    *p = *reinterpret_cast<bf16_t *>(&h);
+}
+
+// one wave per row; d <= 64 * 4 * MAXV
+template <typename TOUT, int MAXV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ x, long ldx,
+                                                        const float *__restrict__ w, const float *__restrict__ b,
+                                                        TOUT *__restrict__ out, long ldo, int rows, int d) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float *xr = x + (long)row * ldx;
+    float4 v[MAXV];
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < d) {
+            v[i] = *reinterpret_cast<const float4 *>(xr + c);
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        } else {
+            v[i] = make_float4(0, 0, 0, 0);
+        }
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float s2 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < d) {
+            v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+            s2 += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(s2) / (float)d + 1e-5f);
+    TOUT *o = out + (long)row * ldo;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < d) {
+            const float4 ww = *reinterpret_cast<const float4 *>(w + c);
+            const float4 bb = *reinterpret_cast<const float4 *>(b + c);
+            store_out(o + c + 0, v[i].x * rstd * ww.x + bb.x);
+            store_out(o + c + 1, v[i].y * rstd * ww.y + bb.y);
+            store_out(o + c + 2, v[i].z * rstd * ww.z + bb.z);
+            store_out(o + c + 3, v[i].w * rstd * ww.w + bb.w);
+        }
+    }
+}
+
+// one wave per row of n (<= 64*MAXE) scores
+template <typename TOUT, int MAXE>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float *__restrict__ s, long lds_, TOUT *__restrict__ out,
+                                                           long ldo, long rows, int n, int n_pad, float scale) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float *sr = s + row * lds_;
+    float v[MAXE];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < MAXE; ++i) {
+        const int c = i * 64 + lane;
+        v[i] = c < n ? sr[c] * scale : -INFINITY;
+        mx = fmaxf(mx, v[i]);
+    }
+    mx = wave_max(mx);
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < MAXE; ++i) {
+        const int c = i * 64 + lane;
+        v[i] = c < n ? expf(v[i] - mx) : 0.0f;
+        sum += v[i];
+    }
+    const float inv = 1.0f / wave_sum(sum);
+    TOUT *o = out + row * ldo;
+#pragma unroll
+    for (int i = 0; i < MAXE; ++i) {
+        const int c = i * 64 + lane;
+        if (c < n_pad) store_out(o + c, v[i] * inv);
+    }
+}
+
+__global__ __launch_bounds__(256) void convert_kernel(const float *__restrict__ src, bf16_t *__restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) store_out(dst + i, src[i]);
+}
+
+}  // namespace
+
+void launch_layernorm(const float *x, long ldx, const float *w, const float *b, void *out, long ldo, DType out_t,
+                      int rows, int d, hipStream_t st) {
+    MW_CHECK(rows > 0 && d > 0 && d % 4 == 0 && d <= 64 * 4 * 8, "layernorm: d must be a multiple of 4, <= 2048");
+    MW_CHECK(ldx % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0 && ((uintptr_t)b % 16) == 0,
+             "layernorm: alignment");
+    dim3 grid(ceil_div(rows, 4));
+    if (out_t == DType::F32)
+        hipLaunchKernelGGL((layernorm_kernel<float, 8>), grid, dim3(256), 0, st, x, ldx, w, b, (float *)out, ldo, rows, d);
+    else
+        hipLaunchKernelGGL((layernorm_kernel<bf16_t, 8>), grid, dim3(256), 0, st, x, ldx, w, b, (bf16_t *)out, ldo, rows,
+                           d);
+    MW_HIP(hipGetLastError());
+}
+
+void launch_softmax_rows(const float *s, long lds_, void *out, long ldo, DType out_t, long rows, int n, int n_pad,
+                         float scale, hipStream_t st) {
+    MW_CHECK(rows > 0 && n > 0 && n <= n_pad && n_pad <= 64 * 24, "softmax: row length out of range");
+    MW_CHECK(ldo >= n_pad && lds_ >= n, "softmax: strides");
+    dim3 grid((unsigned)ceil_div<long>(rows, 4));
+    if (out_t == DType::F32)
+        hipLaunchKernelGGL((softmax_rows_kernel<float, 24>), grid, dim3(256), 0, st, s, lds_, (float *)out, ldo, rows, n,
+                           n_pad, scale);
+    else
+        hipLaunchKernelGGL((softmax_rows_kernel<bf16_t, 24>), grid, dim3(256), 0, st, s, lds_, (bf16_t *)out, ldo, rows, n,
+                           n_pad, scale);
+    MW_HIP(hipGetLastError());
+}
+
+void launch_fill_zero(void *p, size_t bytes, hipStream_t st) { MW_HIP(hipMemsetAsync(p, 0, bytes, st)); }
+
+void launch_convert(const float *src, void *dst, DType dt, size_t n, hipStream_t st) {
+    if (dt == DType::F32) {
+        MW_HIP(hipMemcpyAsync(dst, src, n * 4, hipMemcpyDeviceToDevice, st));
+        return;
+    }
+    dim3 grid((unsigned)std::min<size_t>(ceil_div<size_t>(n, 256), 4096));
+    hipLaunchKernelGGL(convert_kernel, grid, dim3(256), 0, st, src, (bf16_t *)dst, n);
+    MW_HIP(hipGetLastError());
+}
+
+}  // namespace mw

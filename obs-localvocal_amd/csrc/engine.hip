@@ -1,0 +1,860 @@
+// engine.hip — context creation, the stage pipelines (mel / encoder / decoder) and the whisper_full driver.
+//
+// The driver restates whisper.cpp v1.6.2's whisper_full_with_state — windows of 30 s,
+// temperature fallback, greedy / beam bookkeeping, timestamp-driven seeking, segment assembly — as
+// LocalVocal uses it (/root/reference/src/whisper-utils/whisper-processing.cpp:218-258), but every
+// arithmetic step runs on the GPU: the host only keeps token sequences and launches kernels.
+#include "engine.hpp"
+
+#include <chrono>
+#include <cmath>
+#include <map>
+#include <regex>
+
+namespace mw {
+
+namespace {
+
+double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+template <typename T> void dev_alloc(T *&p, size_t n) {
+    MW_HIP(hipMalloc((void **)&p, std::max<size_t>(n, 1) * sizeof(T)));
+}
+void dev_alloc_bytes(void *&p, size_t bytes) { MW_HIP(hipMalloc(&p, std::max<size_t>(bytes, 16))); }
+
+const char *const k_non_speech[] = {
+    "\"", "#", "(", ")", "*", "+", "/", ":", ";", "<", "=", ">", "@", "[", "\\", "]", "^", "_", "`", "{", "|", "}",
+    "~", "「", "」", "『", "』", "<<", ">>", "<<<", ">>>", "--", "---", "-(", "-[", "('", "(\"", "((", "))", "(((",
+    ")))", "[[", "]]", "{{", "}}", "♪♪", "♪♪♪", "♩", "♪", "♫", "♬", "♭", "♮", "♯"};
+
+}  // namespace
+
+Context::~Context() {
+    (void)hipSetDevice(device);
+    void *ptrs[] = {d_pcm, d_mel_raw, d_mel, d_gmax, d_conv_in, d_x1, d_h, d_qk, d_vt, d_p, d_att, d_ff, d_enc_out, d_x,
+                    d_s, d_cross, d_kself, d_vself, d_kv_idx[0], d_kv_idx[1], d_tokens, d_pos, d_slot, d_rows, d_xd, d_q,
+                    d_attd, d_ffd, d_part, d_logits, d_work, d_suppress, d_row_state, d_row_res};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (h_ints) (void)hipHostFree(h_ints);
+    if (h_row_state) (void)hipHostFree(h_row_state);
+    if (h_row_res) (void)hipHostFree(h_row_res);
+    if (st) (void)hipStreamDestroy(st);
+}
+
+std::unique_ptr<Context> create_context(const unsigned char *data, size_t size, int device, DType wt) {
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+        throw std::runtime_error("no HIP device available: this engine has no CPU path");
+    if (device < 0 || device >= n_dev) throw std::runtime_error("gpu_device out of range");
+    MW_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    MW_HIP(hipGetDeviceProperties(&prop, device));
+    if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
+        throw std::runtime_error(std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+    std::unique_ptr<Context> c(new Context());
+    c->device = device;
+    MW_HIP(hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking));
+    load_model(c->model, data, size, wt, c->st);
+    const HParams &hp = c->model.hp;
+    const size_t d = hp.n_audio_state, T = hp.n_audio_ctx, ws = dtype_size(wt), H = hp.n_audio_head;
+    const size_t L = hp.n_text_layer, TC = hp.n_text_ctx, nv = hp.n_vocab;
+    c->tp = (int)((T + 63) / 64 * 64);
+    // encoder workspace (sized for the full audio context)
+    dev_alloc_bytes(c->d_conv_in, (2 * T + 2) * hp.n_mels * ws);
+    dev_alloc_bytes(c->d_x1, (2 * T + 1) * d * ws);
+    dev_alloc(c->d_x, T * d);
+    dev_alloc_bytes(c->d_h, T * d * ws);
+    dev_alloc_bytes(c->d_qk, T * 2 * d * ws);
+    dev_alloc_bytes(c->d_vt, d * c->tp * ws);
+    dev_alloc(c->d_s, H * T * c->tp);
+    dev_alloc_bytes(c->d_p, H * T * c->tp * ws);
+    dev_alloc_bytes(c->d_att, T * d * ws);
+    dev_alloc_bytes(c->d_ff, T * 4 * d * ws);
+    dev_alloc_bytes(c->d_enc_out, T * d * ws);
+    dev_alloc_bytes(c->d_cross, L * 2 * T * d * ws);
+    MW_HIP(hipMemsetAsync(c->d_x1, 0, (2 * T + 1) * d * ws, c->st));  // row 0 is the conv2 left zero pad
+    MW_HIP(hipMemsetAsync(c->d_vt, 0, d * c->tp * ws, c->st));        // pad columns stay zero
+    MW_HIP(hipMemsetAsync(c->d_p, 0, H * T * c->tp * ws, c->st));
+    // decoder workspace
+    dev_alloc_bytes(c->d_kself, L * KV_SLOTS * TC * d * ws);
+    dev_alloc_bytes(c->d_vself, L * KV_SLOTS * TC * d * ws);
+    for (int i = 0; i < 2; ++i) {
+        dev_alloc(c->d_kv_idx[i], KV_SLOTS * TC);
+        MW_HIP(hipMemsetAsync(c->d_kv_idx[i], 0, KV_SLOTS * TC * sizeof(int), c->st));
+    }
+    dev_alloc(c->d_tokens, TC);
+    dev_alloc(c->d_pos, TC);
+    dev_alloc(c->d_slot, TC);
+    dev_alloc(c->d_rows, TC);
+    dev_alloc(c->d_xd, TC * d);
+    dev_alloc(c->d_q, TC * d);
+    dev_alloc(c->d_attd, TC * d);
+    dev_alloc(c->d_ffd, TC * 4 * d);
+    dev_alloc(c->d_part, TC * H * CROSS_SPLITS_MAX * 66);
+    dev_alloc(c->d_logits, (size_t)LOGIT_ROWS * nv);
+    dev_alloc(c->d_work, (size_t)LOGIT_ROWS * nv);
+    dev_alloc(c->d_suppress, nv);
+    dev_alloc(c->d_row_state, LOGIT_ROWS);
+    dev_alloc(c->d_row_res, LOGIT_ROWS);
+    MW_HIP(hipHostMalloc((void **)&c->h_ints, 4 * TC * sizeof(int)));
+    MW_HIP(hipHostMalloc((void **)&c->h_row_state, LOGIT_ROWS * sizeof(LogitsRowState)));
+    MW_HIP(hipHostMalloc((void **)&c->h_row_res, LOGIT_ROWS * sizeof(LogitsRowResult)));
+    c->decoders[0].rng = std::mt19937(0);
+    c->n_ctx_cur = (int)T;
+    MW_HIP(hipStreamSynchronize(c->st));
+    log_msg(LOG_INFO, "mi355_whisper: model loaded (%zu params, %s weights, %.1f MB arena) on device %d (%s)\n",
+            c->model.n_params, wt == DType::F32 ? "fp32" : "bf16", c->model.arena_used / 1048576.0, device,
+            prop.gcnArchName);
+    return c;
+}
+
+// ------------------------------------------------------------------------------------------
+// mel (A.2)
+// ------------------------------------------------------------------------------------------
+void pcm_to_mel(Context &c, const float *pcm, int n_samples, bool pcm_on_device) {
+    MW_CHECK(pcm && n_samples > 0, "pcm_to_mel: empty input");
+    const int n_mel = c.model.hp.n_mels;
+    const double t0 = now_ms();
+    if ((size_t)n_samples > c.pcm_cap) {
+        if (c.d_pcm) MW_HIP(hipFree(c.d_pcm));
+        c.d_pcm = nullptr;
+        c.pcm_cap = std::max<size_t>(n_samples, 30 * WHISPER_SAMPLE_RATE + 640);
+        dev_alloc(c.d_pcm, c.pcm_cap);
+    }
+    MW_HIP(hipMemcpyAsync(c.d_pcm, pcm, (size_t)n_samples * 4, pcm_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                          c.st));
+    // reference frame counts: 30 s of zero padding at the end, 200-sample reflect pad at the start
+    const int n_len = (n_samples + 30 * WHISPER_SAMPLE_RATE) / MEL_HOP;
+    const int n_real = n_samples + MEL_N_FFT / 2;
+    const int n_active = std::min(n_real / MEL_HOP + 1, n_len);
+    if ((size_t)n_len > c.mel_cap_frames) {
+        if (c.d_mel_raw) MW_HIP(hipFree(c.d_mel_raw));
+        if (c.d_mel) MW_HIP(hipFree(c.d_mel));
+        c.d_mel_raw = c.d_mel = nullptr;
+        c.mel_cap_frames = std::max<size_t>(n_len, 6000);
+        dev_alloc(c.d_mel_raw, c.mel_cap_frames * n_mel);
+        dev_alloc(c.d_mel, c.mel_cap_frames * n_mel);
+        if (!c.d_gmax) dev_alloc(c.d_gmax, 16);
+    }
+    launch_mel_frames(c.d_pcm, 0, n_samples, 1, c.model.d_mel_tab, c.d_mel_raw, (long)c.mel_cap_frames * n_mel, n_active,
+                      n_mel, c.d_gmax, c.st);
+    launch_mel_normalize(c.d_mel_raw, 0, c.d_mel, 0, n_len, n_active, n_mel, 1, c.d_gmax, c.st);
+    c.n_len = n_len;
+    c.n_len_org = 1 + (n_samples + MEL_N_FFT / 2 - MEL_N_FFT) / MEL_HOP;
+    c.tm.mel_ms += now_ms() - t0;
+}
+
+// ------------------------------------------------------------------------------------------
+// encoder + cross-KV (A.3)
+// ------------------------------------------------------------------------------------------
+void encode(Context &c, int seek) {
+    const Model &m = c.model;
+    const HParams &hp = m.hp;
+    const DType wt = m.wt;
+    const size_t ws = dtype_size(wt);
+    const int n_ctx = c.exp_n_audio_ctx > 0 ? c.exp_n_audio_ctx : hp.n_audio_ctx;
+    MW_CHECK(n_ctx <= hp.n_audio_ctx, "audio_ctx larger than the model's");
+    const int d = hp.n_audio_state, H = hp.n_audio_head, n_mel = hp.n_mels, T2 = 2 * n_ctx;
+    const int tp = (n_ctx + 63) / 64 * 64;
+    hipStream_t st = c.st;
+    const double t0 = now_ms();
+    c.n_ctx_cur = n_ctx;
+    MW_CHECK(c.d_mel != nullptr, "encode called before any mel was computed");
+    launch_mel_window(c.d_mel, 0, c.n_len, seek, T2, n_mel, 1, c.d_conv_in, (long)(T2 + 2) * n_mel, wt, st);
+    {   // conv1 as a GEMM over the overlapping row view: output row t <- padded rows t, t+1, t+2
+        GemmArgs g;
+        g.A = c.d_conv_in; g.lda = n_mel; g.W = m.conv1_w; g.ldw = 3 * n_mel;
+        g.C = (char *)c.d_x1 + (size_t)d * ws; g.ldc = d;  // x1 row 0 stays zero (conv2's left pad)
+        g.bias = m.conv1_b; g.M = T2; g.N = d; g.K = 3 * n_mel; g.act = ACT_GELU;
+        launch_gemm(g, wt, wt, st);
+    }
+    {   // conv2, stride 2: output row t <- padded x1 rows 2t, 2t+1, 2t+2; + positional embedding
+        GemmArgs g;
+        g.A = c.d_x1; g.lda = 2 * d; g.W = m.conv2_w; g.ldw = 3 * d;
+        g.C = c.d_x; g.ldc = d; g.bias = m.conv2_b; g.M = n_ctx; g.N = d; g.K = 3 * d; g.act = ACT_GELU;
+        g.R = m.enc_pe; g.ldr = d;
+        launch_gemm(g, wt, DType::F32, st);
+    }
+    for (int l = 0; l < hp.n_audio_layer; ++l) {
+        const EncLayer &e = m.enc[l];
+        launch_layernorm(c.d_x, d, e.ln1_w, e.ln1_b, c.d_h, d, wt, n_ctx, d, st);
+        {
+            GemmArgs g;  // Q | K
+            g.A = c.d_h; g.lda = d; g.W = e.qk_w; g.ldw = d; g.C = c.d_qk; g.ldc = 2 * d; g.bias = e.qk_b;
+            g.M = n_ctx; g.N = 2 * d; g.K = d;
+            launch_gemm(g, wt, wt, st);
+        }
+        {
+            GemmArgs g;  // V, stored transposed [d][tp]
+            g.A = c.d_h; g.lda = d; g.W = e.v_w; g.ldw = d; g.C = c.d_vt; g.ldc = tp; g.bias = e.v_b;
+            g.M = n_ctx; g.N = d; g.K = d; g.trans_c = 1;
+            launch_gemm(g, wt, wt, st);
+        }
+        {
+            GemmArgs g;  // S_h = Q_h K_h^T, batched over heads
+            g.A = c.d_qk; g.lda = 2 * d; g.W = (char *)c.d_qk + (size_t)d * ws; g.ldw = 2 * d;
+            g.C = c.d_s; g.ldc = tp; g.M = n_ctx; g.N = n_ctx; g.K = 64;
+            g.nz1 = H; g.sA1 = 64; g.sW1 = 64; g.sC1 = (long)n_ctx * tp;
+            launch_gemm(g, wt, DType::F32, st);
+        }
+        launch_softmax_rows(c.d_s, tp, c.d_p, tp, wt, (long)H * n_ctx, n_ctx, tp, 1.0f / sqrtf(64.0f), st);
+        {
+            GemmArgs g;  // O_h = P_h V_h
+            g.A = c.d_p; g.lda = tp; g.W = c.d_vt; g.ldw = tp; g.C = c.d_att; g.ldc = d;
+            g.M = n_ctx; g.N = 64; g.K = tp;
+            g.nz1 = H; g.sA1 = (long)n_ctx * tp; g.sW1 = (long)64 * tp; g.sC1 = 64;
+            launch_gemm(g, wt, wt, st);
+        }
+        {
+            GemmArgs g;  // x += att Wo^T + bo
+            g.A = c.d_att; g.lda = d; g.W = e.out_w; g.ldw = d; g.C = c.d_x; g.ldc = d; g.bias = e.out_b;
+            g.R = c.d_x; g.ldr = d; g.M = n_ctx; g.N = d; g.K = d;
+            launch_gemm(g, wt, DType::F32, st);
+        }
+        launch_layernorm(c.d_x, d, e.ln2_w, e.ln2_b, c.d_h, d, wt, n_ctx, d, st);
+        {
+            GemmArgs g;
+            g.A = c.d_h; g.lda = d; g.W = e.fc1_w; g.ldw = d; g.C = c.d_ff; g.ldc = 4 * d; g.bias = e.fc1_b;
+            g.M = n_ctx; g.N = 4 * d; g.K = d; g.act = ACT_GELU;
+            launch_gemm(g, wt, wt, st);
+        }
+        {
+            GemmArgs g;
+            g.A = c.d_ff; g.lda = 4 * d; g.W = e.fc2_w; g.ldw = 4 * d; g.C = c.d_x; g.ldc = d; g.bias = e.fc2_b;
+            g.R = c.d_x; g.ldr = d; g.M = n_ctx; g.N = d; g.K = 4 * d;
+            launch_gemm(g, wt, DType::F32, st);
+        }
+    }
+    launch_layernorm(c.d_x, d, m.ln_post_w, m.ln_post_b, c.d_enc_out, d, wt, n_ctx, d, st);
+    {   // cross K (scaled by dh^-1/4, no bias) and V (+bias) of every decoder layer, batched over layers
+        const int L = hp.n_text_layer;
+        const long per_layer = 2L * hp.n_audio_ctx * d;
+        GemmArgs g;
+        g.A = c.d_enc_out; g.lda = d; g.W = m.ckv_w; g.ldw = d; g.C = c.d_cross; g.ldc = d;
+        g.M = n_ctx; g.N = d; g.K = d; g.nz1 = L; g.sW1 = 2L * d * d; g.sC1 = per_layer;
+        g.alpha = powf(64.0f, -0.25f);
+        launch_gemm(g, wt, wt, st);
+        GemmArgs v = g;
+        v.W = (char *)m.ckv_w + (size_t)d * d * ws;
+        v.C = (char *)c.d_cross + (size_t)hp.n_audio_ctx * d * ws;
+        v.bias = m.ckv_b + d; v.sB1 = 2L * d; v.alpha = 1.0f;
+        launch_gemm(v, wt, wt, st);
+    }
+    c.tm.n_encode++;
+    c.tm.encode_ms += now_ms() - t0;
+}
+
+// ------------------------------------------------------------------------------------------
+// decoder (A.4)
+// ------------------------------------------------------------------------------------------
+void kv_clear(Context &c) {
+    const size_t bytes = (size_t)KV_SLOTS * c.model.hp.n_text_ctx * sizeof(int);
+    MW_HIP(hipMemsetAsync(c.d_kv_idx[0], 0, bytes, c.st));
+    MW_HIP(hipMemsetAsync(c.d_kv_idx[1], 0, bytes, c.st));
+    c.kv_cur = 0;
+}
+
+void kv_reorder(Context &c, const int *src, int n_past) {
+    BeamSrc b;
+    for (int j = 0; j < KV_SLOTS; ++j) b.src[j] = src[j];
+    launch_kv_reorder(c.d_kv_idx[c.kv_cur], c.d_kv_idx[c.kv_cur ^ 1], b, n_past, c.model.hp.n_text_ctx, c.st);
+    c.kv_cur ^= 1;
+}
+
+void decode(Context &c, const int *tokens, const int *pos, const int *slot, int n, const int *logit_rows,
+            int n_logit_rows) {
+    const Model &m = c.model;
+    const HParams &hp = m.hp;
+    const DType wt = m.wt;
+    const size_t ws = dtype_size(wt);
+    const int d = hp.n_text_state, H = hp.n_text_head, TC = hp.n_text_ctx, n_ctx = c.n_ctx_cur;
+    MW_CHECK(n > 0 && n <= TC, "decode: batch size out of range");
+    MW_CHECK(n_logit_rows >= 0 && n_logit_rows <= LOGIT_ROWS, "decode: too many logits rows");
+    for (int i = 0; i < n; ++i) {
+        MW_CHECK(tokens[i] >= 0 && tokens[i] < hp.n_vocab, "decode: token id out of range");
+        MW_CHECK(pos[i] >= 0 && pos[i] < TC, "decode: position beyond n_text_ctx");
+        MW_CHECK(slot[i] >= 0 && slot[i] < KV_SLOTS, "decode: bad sequence slot");
+    }
+    for (int i = 0; i < n_logit_rows; ++i) MW_CHECK(logit_rows[i] >= 0 && logit_rows[i] < n, "decode: bad logits row");
+    hipStream_t st = c.st;
+    const double t0 = now_ms();
+    // the pinned staging block may still be read by the previous call's copies
+    MW_HIP(hipStreamSynchronize(st));
+    int *hi = c.h_ints;
+    memcpy(hi, tokens, n * sizeof(int));
+    memcpy(hi + TC, pos, n * sizeof(int));
+    memcpy(hi + 2 * TC, slot, n * sizeof(int));
+    memcpy(hi + 3 * TC, logit_rows, n_logit_rows * sizeof(int));
+    MW_HIP(hipMemcpyAsync(c.d_tokens, hi, n * sizeof(int), hipMemcpyHostToDevice, st));
+    MW_HIP(hipMemcpyAsync(c.d_pos, hi + TC, n * sizeof(int), hipMemcpyHostToDevice, st));
+    MW_HIP(hipMemcpyAsync(c.d_slot, hi + 2 * TC, n * sizeof(int), hipMemcpyHostToDevice, st));
+    if (n_logit_rows)
+        MW_HIP(hipMemcpyAsync(c.d_rows, hi + 3 * TC, n_logit_rows * sizeof(int), hipMemcpyHostToDevice, st));
+    launch_embed(c.d_tokens, c.d_pos, m.tok_emb, wt, m.dec_pe, c.d_xd, n, d, st);
+    const float qk_scale = powf(64.0f, -0.25f);
+    const int splits = std::min(CROSS_SPLITS_MAX, std::max(ceil_div(n_ctx, 256), ceil_div(n_ctx, 128)));
+    const size_t kv_layer = (size_t)KV_SLOTS * TC * d * ws;
+    for (int l = 0; l < hp.n_text_layer; ++l) {
+        const DecLayer &e = m.dec[l];
+        {
+            GemvArgs g;  // LN + Q|K|V; K and V go straight into the cache
+            g.x = c.d_xd; g.ldx = d; g.n = n; g.W = e.qkv_w; g.bias = e.qkv_b; g.N = 3 * d; g.K = d;
+            g.ln_w = e.ln1_w; g.ln_b = e.ln1_b; g.out = c.d_q; g.ldo = d; g.qkv = 1; g.qk_scale = qk_scale;
+            g.kcache = (char *)c.d_kself + l * kv_layer; g.vcache = (char *)c.d_vself + l * kv_layer;
+            g.kv_t = wt; g.d_slot = c.d_slot; g.d_pos = c.d_pos; g.n_text_ctx = TC;
+            launch_gemv(g, wt, st);
+        }
+        launch_self_attn(c.d_q, (char *)c.d_kself + l * kv_layer, (char *)c.d_vself + l * kv_layer, wt, c.d_slot, c.d_pos,
+                         c.d_kv_idx[c.kv_cur], c.d_attd, n, H, d, TC, st);
+        {
+            GemvArgs g;
+            g.x = c.d_attd; g.ldx = d; g.n = n; g.W = e.out_w; g.bias = e.out_b; g.N = d; g.K = d;
+            g.out = c.d_xd; g.ldo = d; g.R = c.d_xd;
+            launch_gemv(g, wt, st);
+        }
+        {
+            GemvArgs g;  // LN + cross query (scaled)
+            g.x = c.d_xd; g.ldx = d; g.n = n; g.W = e.cq_w; g.bias = e.cq_b; g.N = d; g.K = d;
+            g.ln_w = e.lnc_w; g.ln_b = e.lnc_b; g.out = c.d_q; g.ldo = d; g.out_scale = qk_scale;
+            launch_gemv(g, wt, st);
+        }
+        const char *ck = (const char *)c.d_cross + (size_t)l * 2 * hp.n_audio_ctx * d * ws;
+        launch_cross_attn(c.d_q, ck, ck + (size_t)hp.n_audio_ctx * d * ws, wt, c.d_part, c.d_attd, n, H, d, n_ctx, splits,
+                          st);
+        {
+            GemvArgs g;
+            g.x = c.d_attd; g.ldx = d; g.n = n; g.W = e.co_w; g.bias = e.co_b; g.N = d; g.K = d;
+            g.out = c.d_xd; g.ldo = d; g.R = c.d_xd;
+            launch_gemv(g, wt, st);
+        }
+        {
+            GemvArgs g;
+            g.x = c.d_xd; g.ldx = d; g.n = n; g.W = e.fc1_w; g.bias = e.fc1_b; g.N = 4 * d; g.K = d;
+            g.ln_w = e.ln2_w; g.ln_b = e.ln2_b; g.act = ACT_GELU; g.out = c.d_ffd; g.ldo = 4 * d;
+            launch_gemv(g, wt, st);
+        }
+        {
+            GemvArgs g;
+            g.x = c.d_ffd; g.ldx = 4 * d; g.n = n; g.W = e.fc2_w; g.bias = e.fc2_b; g.N = d; g.K = 4 * d;
+            g.out = c.d_xd; g.ldo = d; g.R = c.d_xd;
+            launch_gemv(g, wt, st);
+        }
+    }
+    if (n_logit_rows > 0) {
+        GemvArgs g;  // final LN + tied-embedding logits, only for the rows that are sampled from
+        g.x = c.d_xd; g.ldx = d; g.n = n_logit_rows; g.W = m.tok_emb; g.N = hp.n_vocab; g.K = d;
+        g.ln_w = m.dec_ln_w; g.ln_b = m.dec_ln_b; g.out = c.d_logits; g.ldo = hp.n_vocab; g.d_rows = c.d_rows;
+        launch_gemv(g, wt, st);
+    }
+    c.n_logit_rows = n_logit_rows;
+    c.tm.n_decode++;
+    c.tm.decode_ms += now_ms() - t0;
+}
+
+// ------------------------------------------------------------------------------------------
+// logits rules: static mask (A.5 steps 3-6) built on the host once per parameter set
+// ------------------------------------------------------------------------------------------
+void upload_suppress_mask(Context &c, const whisper_full_params &p) {
+    const Vocab &v = c.model.vocab;
+    std::string key = std::string(p.no_timestamps ? "1" : "0") + (p.tdrz_enable ? "1" : "0") +
+                      (p.suppress_non_speech_tokens ? "1" : "0") + (c.force_decode_steps > 0 ? "1" : "0") + "|" +
+                      (p.suppress_regex ? p.suppress_regex : "");
+    if (key == c.suppress_key) return;
+    std::vector<unsigned char> mask(v.n_vocab, 0);
+    mask[v.not_] = 1;
+    if (c.force_decode_steps > 0) mask[v.eot] = 1;  // bench-only extension
+    if (p.no_timestamps)
+        for (int i = v.beg; i < v.n_vocab; ++i) mask[i] = 1;
+    mask[v.sot] = 1;
+    mask[v.nosp] = 1;
+    if (!p.tdrz_enable) mask[v.solm] = 1;
+    mask[v.translate] = 1;
+    mask[v.transcribe] = 1;
+    mask[v.prev] = 1;
+    for (int i = 0; i < N_LANGS; ++i)
+        if (v.lang_token(i) < v.n_vocab) mask[v.lang_token(i)] = 1;
+    if (p.suppress_regex && p.suppress_regex[0]) {
+        std::regex re(p.suppress_regex);
+        for (const auto &kv : v.token_to_id)
+            if (std::regex_match(kv.first, re)) mask[kv.second] = 1;
+    }
+    if (p.suppress_non_speech_tokens) {
+        for (const char *t : k_non_speech)
+            for (const std::string &s : {std::string(t), std::string(" ") + t}) {
+                auto it = v.token_to_id.find(s);
+                if (it != v.token_to_id.end()) mask[it->second] = 1;
+            }
+        for (const char *t : {" -", " '"}) {
+            auto it = v.token_to_id.find(t);
+            if (it != v.token_to_id.end()) mask[it->second] = 1;
+        }
+    }
+    MW_HIP(hipMemcpyAsync(c.d_suppress, mask.data(), mask.size(), hipMemcpyHostToDevice, c.st));
+    MW_HIP(hipStreamSynchronize(c.st));  // mask is a stack-lifetime host buffer
+    c.suppress_key = key;
+}
+
+LogitsParams make_logits_params(const Context &c, const whisper_full_params &p, float temperature, int n_samples) {
+    const Vocab &v = c.model.vocab;
+    LogitsParams lp;
+    lp.n_vocab = v.n_vocab;
+    lp.eot = v.eot;
+    lp.beg = v.beg;
+    auto it = v.token_to_id.find(" ");
+    lp.space_id = it != v.token_to_id.end() ? it->second : -1;
+    lp.suppress_blank = p.suppress_blank ? 1 : 0;
+    lp.temperature = temperature;
+    lp.tid0_initial = -1;
+    if (p.max_initial_ts > 0.0f) {
+        const float precision = float(WHISPER_CHUNK_SIZE) / c.model.hp.n_audio_ctx;
+        lp.tid0_initial = (int)std::round(p.max_initial_ts / precision);
+    }
+    lp.n_samples = n_samples;
+    return lp;
+}
+
+namespace {
+
+// run the rules + sampler for the listed decoders; row j of the launch serves decoders[idx[j]]
+void process_and_sample(Context &c, const whisper_full_params &params, float t_cur, const std::vector<int> &dec_idx,
+                        const std::vector<int> &logits_row, int n_samples, bool eot_forced_off) {
+    const double t0 = now_ms();
+    const int n = (int)dec_idx.size();
+    MW_CHECK(n > 0 && n <= LOGIT_ROWS, "sampler: row count");
+    const Vocab &v = c.model.vocab;
+    for (int r = 0; r < n; ++r) {
+        Decoder &d = c.decoders[dec_idx[r]];
+        const auto &tk = d.sequence.tokens;
+        LogitsRowState &s = c.h_row_state[r];
+        s.logits_row = logits_row[r];
+        s.n_sampled = (int)tk.size();
+        s.last_is_ts = !tk.empty() && tk.back().id >= v.beg;
+        s.penult_is_ts = tk.size() < 2 || tk[tk.size() - 2].id >= v.beg;
+        s.has_ts = d.has_ts;
+        s.seek_delta = d.seek_delta;
+        for (int k = 0; k < n_samples; ++k) s.u[k] = std::generate_canonical<double, 53>(d.rng);
+    }
+    LogitsParams lp = make_logits_params(c, params, t_cur, n_samples);
+    (void)eot_forced_off;
+    MW_HIP(hipMemcpyAsync(c.d_row_state, c.h_row_state, n * sizeof(LogitsRowState), hipMemcpyHostToDevice, c.st));
+    launch_process_logits(c.d_logits, v.n_vocab, c.d_suppress, lp, c.d_row_state, c.d_row_res, n, c.d_work, nullptr,
+                          nullptr, nullptr, c.st);
+    MW_HIP(hipMemcpyAsync(c.h_row_res, c.d_row_res, n * sizeof(LogitsRowResult), hipMemcpyDeviceToHost, c.st));
+    MW_HIP(hipStreamSynchronize(c.st));
+    for (int r = 0; r < n; ++r) c.decoders[dec_idx[r]].sampled = c.h_row_res[r];
+    c.tm.n_sample++;
+    c.tm.sample_ms += now_ms() - t0;
+}
+
+whisper_token_data make_token(const Vocab &v, const LogitsRowResult &r, int k, int tid_default) {
+    whisper_token_data t = {r.id[k], r.tid >= 0 ? r.tid : tid_default, r.p[k], r.plog[k], r.pt, r.ptsum, -1, -1, -1, 0.0f};
+    if (t.id >= v.beg) {
+        t.tid = t.id;
+        t.pt = t.p;
+    }
+    return t;
+}
+
+void sequence_score(const whisper_full_params &params, Sequence &s) {
+    if (s.result_len == 0) return;
+    double result = 0.0;
+    for (int i = 0; i < s.result_len; ++i) result += s.tokens[i].plog;
+    s.sum_logprobs = result;
+    s.avg_logprobs = result / s.result_len;
+    double penalty = s.result_len;
+    if (params.length_penalty > 0.0f) penalty = pow((5.0 + penalty) / 6.0, params.length_penalty);
+    s.score = result / penalty;
+    const int n = 32;
+    int cnt = 0;
+    double entropy = 0.0;
+    std::map<int, int> counts;
+    for (int i = std::max(0, s.result_len - n); i < s.result_len; ++i) {
+        counts[s.tokens[i].id]++;
+        cnt++;
+    }
+    for (const auto &kv : counts) {
+        const double p = kv.second / (double)cnt;
+        entropy -= p * log(p);
+    }
+    s.entropy = entropy;
+}
+
+bool seq_tokens_equal(const Sequence &a, const Sequence &b) {
+    if (a.tokens.size() != b.tokens.size()) return false;
+    for (size_t i = 0; i < a.tokens.size(); ++i)
+        if (a.tokens[i].id != b.tokens[i].id) return false;
+    return true;
+}
+
+}  // namespace
+
+int lang_auto_detect(Context &c, int offset_ms, float *lang_probs) {
+    const Vocab &v = c.model.vocab;
+    const int seek = offset_ms / 10;
+    if (seek < 0) return -1;
+    if (seek >= c.n_len_org) return -2;
+    if (!v.is_multilingual()) return -3;
+    encode(c, seek);
+    kv_clear(c);
+    const int tok = v.sot, pos = 0, slot = 0, row = 0;
+    decode(c, &tok, &pos, &slot, 1, &row, 1);
+    const int nl = std::min(N_LANGS, v.num_languages());
+    std::vector<float> lg(nl);
+    MW_HIP(hipMemcpyAsync(lg.data(), c.d_logits + v.lang_token(0), nl * sizeof(float), hipMemcpyDeviceToHost, c.st));
+    MW_HIP(hipStreamSynchronize(c.st));
+    std::vector<std::pair<double, int>> lid;
+    for (int i = 0; i < nl; ++i) lid.emplace_back(lg[i], i);
+    std::sort(lid.begin(), lid.end(),
+              [](const std::pair<double, int> &a, const std::pair<double, int> &b) { return a.first > b.first; });
+    const double mx = lid[0].first;
+    double sum = 0;
+    for (auto &kv : lid) {
+        kv.first = exp(kv.first - mx);
+        sum += kv.first;
+    }
+    for (auto &kv : lid) kv.first /= sum;
+    if (lang_probs)
+        for (auto &kv : lid) lang_probs[kv.second] = (float)kv.first;
+    return lid[0].second;
+}
+
+// ------------------------------------------------------------------------------------------
+// whisper_full (A.6)
+// ------------------------------------------------------------------------------------------
+int full(Context &c, whisper_full_params params, const float *samples, int n_samples) {
+    const Model &model = c.model;
+    const Vocab &vocab = model.vocab;
+    const HParams &hp = model.hp;
+    const double t_start = now_ms();
+    if (params.logits_filter_callback || params.grammar_rules) return -10;
+    auto &result_all = c.result_all;
+    result_all.clear();
+    if (n_samples > 0) pcm_to_mel(c, samples, n_samples, false);
+    if (c.d_mel == nullptr) return -2;
+    std::string language = params.language ? params.language : "";
+    if (language.empty() || language == "auto" || params.detect_language) {
+        std::vector<float> probs(N_LANGS, 0.0f);
+        const int id = lang_auto_detect(c, 0, probs.data());
+        if (id < 0) {
+            log_msg(LOG_ERROR, "whisper_full: failed to auto-detect language (%d)\n", id);
+            return -3;
+        }
+        c.lang_id = id;
+        language = lang_str(id);
+        log_msg(LOG_INFO, "whisper_full: auto-detected language: %s (p = %f)\n", language.c_str(), probs[id]);
+        if (params.detect_language) return 0;
+    }
+    const int seek_start = params.offset_ms / 10;
+    const int seek_end = params.duration_ms == 0 ? c.n_len : seek_start + params.duration_ms / 10;
+    if (seek_end < seek_start + 100) {
+        log_msg(LOG_WARN, "whisper_full: input is too short - %d ms < 1000 ms. consider padding the input audio with silence\n",
+                (seek_end - seek_start) * 10);
+        return 0;
+    }
+    std::vector<float> temperatures;
+    if (params.temperature_inc > 0.0f) {
+        for (float t = params.temperature; t < 1.0f + 1e-6f; t += params.temperature_inc) temperatures.push_back(t);
+    } else {
+        temperatures.push_back(params.temperature);
+    }
+    int n_decoders = 1;
+    if (params.strategy == WHISPER_SAMPLING_GREEDY) n_decoders = params.greedy.best_of;
+    else n_decoders = std::max(params.greedy.best_of, params.beam_search.beam_size);
+    n_decoders = std::max(1, n_decoders);
+    if (n_decoders > MAX_DECODERS) {
+        log_msg(LOG_ERROR, "whisper_full: too many decoders requested (%d), max = %d\n", n_decoders, MAX_DECODERS);
+        return -4;
+    }
+    if (params.strategy == WHISPER_SAMPLING_BEAM_SEARCH && params.beam_search.beam_size > MAX_CAND) return -4;
+    for (int j = 1; j < n_decoders; ++j) c.decoders[j].rng = std::mt19937(0);
+    auto &prompt_past = c.prompt_past;
+    if (params.no_context) prompt_past.clear();
+    {
+        std::vector<int> pt;
+        if (!params.prompt_tokens && params.initial_prompt && params.initial_prompt[0]) {
+            pt = vocab.tokenize(params.initial_prompt);
+        } else if (params.prompt_tokens && params.prompt_n_tokens > 0) {
+            pt.assign(params.prompt_tokens, params.prompt_tokens + params.prompt_n_tokens);
+        }
+        if (!pt.empty()) {
+            for (int t : pt) prompt_past.push_back(t);
+            std::rotate(prompt_past.begin(), prompt_past.end() - pt.size(), prompt_past.end());
+        }
+    }
+    if (params.audio_ctx > hp.n_audio_ctx) {
+        log_msg(LOG_ERROR, "whisper_full: audio_ctx is larger than the maximum allowed (%d > %d)\n", params.audio_ctx,
+                hp.n_audio_ctx);
+        return -5;
+    }
+    c.exp_n_audio_ctx = params.audio_ctx;
+    std::vector<int> prompt_init = {vocab.sot};
+    if (vocab.is_multilingual()) {
+        const int id = lang_id(language.c_str());
+        if (id < 0 || id >= vocab.num_languages()) {
+            log_msg(LOG_ERROR, "whisper_full: unknown language '%s'\n", language.c_str());
+            return -9;
+        }
+        c.lang_id = id;
+        prompt_init.push_back(vocab.lang_token(id));
+        prompt_init.push_back(params.translate ? vocab.translate : vocab.transcribe);
+    }
+    if (hp.n_text_layer == 2 && !params.no_timestamps) params.no_timestamps = true;  // distilled models
+    if (params.no_timestamps) prompt_init.push_back(vocab.not_);
+    upload_suppress_mask(c, params);
+    const int fds = c.force_decode_steps;
+    int seek = seek_start;
+    std::vector<int> prompt;
+    struct beam_candidate {
+        int decoder_idx;
+        int seek_delta;
+        bool has_ts;
+        Sequence sequence;
+    };
+    std::vector<std::vector<beam_candidate>> bc_per_dec(n_decoders);
+    std::vector<beam_candidate> beam_candidates;
+    const bool beam = params.strategy == WHISPER_SAMPLING_BEAM_SEARCH;
+
+    while (true) {
+        if (params.progress_callback) {
+            const int progress_cur = (100 * (seek - seek_start)) / (seek_end - seek_start);
+            params.progress_callback(nullptr, nullptr, progress_cur, params.progress_callback_user_data);
+        }
+        if (seek + 100 >= seek_end) break;
+        if (params.encoder_begin_callback &&
+            !params.encoder_begin_callback(nullptr, nullptr, params.encoder_begin_callback_user_data))
+            break;
+        if (params.abort_callback && params.abort_callback(params.abort_callback_user_data)) return -6;
+        encode(c, seek);
+        if (seek > seek_start && seek + 500 >= seek_end) prompt_past.clear();
+        int best_decoder_id = 0;
+        for (int it = 0; it < (int)temperatures.size(); ++it) {
+            const float t_cur = temperatures[it];
+            int n_decoders_cur = 1;
+            if (!beam) {
+                if (t_cur > 0.0f) n_decoders_cur = params.greedy.best_of;
+            } else {
+                n_decoders_cur = t_cur > 0.0f ? params.greedy.best_of : params.beam_search.beam_size;
+            }
+            n_decoders_cur = std::max(1, n_decoders_cur);
+            // number of draws the device sampler makes per decoder row for this temperature
+            const int n_draw = beam ? params.beam_search.beam_size : (t_cur < 1e-6f ? 0 : 1);
+            for (int j = 0; j < n_decoders_cur; ++j) {
+                Decoder &d = c.decoders[j];
+                d.sequence.tokens.clear();
+                d.sequence.result_len = 0;
+                d.sequence.sum_logprobs_all = 0.0;
+                d.sequence.sum_logprobs = -INFINITY;
+                d.sequence.avg_logprobs = -INFINITY;
+                d.sequence.entropy = 0.0;
+                d.sequence.score = -INFINITY;
+                d.seek_delta = 100 * WHISPER_CHUNK_SIZE;
+                d.failed = d.completed = d.has_ts = false;
+            }
+            {
+                prompt.clear();
+                if (!prompt_past.empty() && t_cur < 0.5f && params.n_max_text_ctx > 0) {
+                    const int n_take = std::min(std::min(params.n_max_text_ctx, hp.n_text_ctx / 2), (int)prompt_past.size());
+                    prompt = {vocab.prev};
+                    prompt.insert(prompt.begin() + 1, prompt_past.end() - n_take, prompt_past.end());
+                }
+                prompt.insert(prompt.end(), prompt_init.begin(), prompt_init.end());
+                kv_clear(c);
+                std::vector<int> pos(prompt.size()), slot(prompt.size(), 0);
+                for (size_t i = 0; i < prompt.size(); ++i) pos[i] = (int)i;
+                const int last = (int)prompt.size() - 1;
+                decode(c, prompt.data(), pos.data(), slot.data(), (int)prompt.size(), &last, 1);
+                // every decoder starts from decoder 0's distribution (kv_seq_cp(0, j) == shared index table)
+                std::vector<int> idx(n_decoders_cur), rows(n_decoders_cur, 0);
+                for (int j = 0; j < n_decoders_cur; ++j) idx[j] = j;
+                process_and_sample(c, params, t_cur, idx, rows, n_draw, fds > 0);
+            }
+            for (int i = 0, n_max = hp.n_text_ctx / 2 - 4; i < n_max; ++i) {
+                if (beam)
+                    for (auto &bc : bc_per_dec) bc.clear();
+                for (int j = 0; j < n_decoders_cur; ++j) {
+                    Decoder &d = c.decoders[j];
+                    if (d.completed || d.failed) continue;
+                    if (!beam) {
+                        d.sequence.tokens.push_back(make_token(vocab, d.sampled, 0, 0));
+                        d.sequence.sum_logprobs_all += d.sequence.tokens.back().plog;
+                    } else {
+                        for (int k = 0; k < params.beam_search.beam_size; ++k) {
+                            const whisper_token_data tk = make_token(vocab, d.sampled, k, vocab.beg);
+                            bc_per_dec[j].push_back({j, d.seek_delta, d.has_ts, d.sequence});
+                            bc_per_dec[j].back().sequence.tokens.push_back(tk);
+                            bc_per_dec[j].back().sequence.sum_logprobs_all += tk.plog;
+                        }
+                    }
+                }
+                int src[MAX_DECODERS];
+                for (int j = 0; j < MAX_DECODERS; ++j) src[j] = -1;
+                if (beam) {
+                    beam_candidates.clear();
+                    for (const auto &bc : bc_per_dec) beam_candidates.insert(beam_candidates.end(), bc.begin(), bc.end());
+                    std::sort(beam_candidates.begin(), beam_candidates.end(),
+                              [](const beam_candidate &a, const beam_candidate &b) {
+                                  return a.sequence.sum_logprobs_all > b.sequence.sum_logprobs_all;
+                              });
+                    uint32_t cur_c = 0;
+                    for (int j = 0; j < n_decoders_cur; ++j) {
+                        Decoder &d = c.decoders[j];
+                        if (d.completed || d.failed) continue;
+                        if (cur_c >= beam_candidates.size()) cur_c = 0;
+                        auto &cur = beam_candidates[cur_c++];
+                        while (beam_candidates.size() > cur_c &&
+                               seq_tokens_equal(beam_candidates[cur_c].sequence, cur.sequence) && i > 0)
+                            ++cur_c;
+                        d.seek_delta = cur.seek_delta;
+                        d.has_ts = cur.has_ts;
+                        d.sequence = cur.sequence;
+                        src[j] = cur.decoder_idx;
+                    }
+                } else {
+                    for (int j = 0; j < n_decoders_cur; ++j)
+                        if (!(c.decoders[j].completed || c.decoders[j].failed)) src[j] = j;
+                }
+                for (int j = 0; j < n_decoders_cur; ++j) {
+                    Decoder &d = c.decoders[j];
+                    if (d.completed || d.failed) continue;
+                    auto &has_ts = d.has_ts;
+                    auto &failed = d.failed;
+                    auto &completed = d.completed;
+                    auto &seek_delta = d.seek_delta;
+                    auto &result_len = d.sequence.result_len;
+                    {
+                        const auto &token = d.sequence.tokens.back();
+                        if (token.id > vocab.beg) {
+                            const int seek_delta_new = 2 * (token.id - vocab.beg);
+                            if (has_ts && seek_delta > seek_delta_new && result_len < i) {
+                                failed = true;
+                                continue;
+                            }
+                            seek_delta = seek_delta_new;
+                            result_len = i + 1;
+                            has_ts = true;
+                        }
+                        const bool forced = fds > 0 && i + 1 < fds;
+                        if (!forced && (token.id == vocab.eot || (params.max_tokens > 0 && i >= params.max_tokens) ||
+                                        (has_ts && seek + seek_delta + 100 >= seek_end) || (fds > 0 && i + 1 >= fds))) {
+                            if (result_len == 0 && !params.no_timestamps) {
+                                if (seek + seek_delta + 100 >= seek_end || fds > 0) {
+                                    result_len = i + 1;
+                                } else {
+                                    failed = true;
+                                    continue;
+                                }
+                            }
+                            if (params.single_segment || params.no_timestamps) {
+                                result_len = i + 1;
+                                seek_delta = 100 * WHISPER_CHUNK_SIZE;
+                            }
+                            completed = true;
+                            continue;
+                        }
+                    }
+                    if (i == n_max - 1 && (result_len == 0 || seek_delta < 100 * WHISPER_CHUNK_SIZE / 2)) {
+                        failed = true;
+                        continue;
+                    }
+                }
+                {
+                    bool completed_all = true;
+                    for (int j = 0; j < n_decoders_cur; ++j)
+                        if (!(c.decoders[j].completed || c.decoders[j].failed)) completed_all = false;
+                    if (completed_all) break;
+                }
+                {
+                    std::vector<int> bt, bp, bs, rows, idx;
+                    const int n_past = (int)prompt.size() + i;
+                    if (n_past >= hp.n_text_ctx) return -8;
+                    // sequences that stopped this step no longer need a cache line
+                    for (int j = 0; j < n_decoders_cur; ++j)
+                        if (c.decoders[j].failed || c.decoders[j].completed) src[j] = -1;
+                    kv_reorder(c, src, n_past);
+                    for (int j = 0; j < n_decoders_cur; ++j) {
+                        Decoder &d = c.decoders[j];
+                        if (d.failed || d.completed) continue;
+                        d.i_batch = (int)bt.size();
+                        rows.push_back(d.i_batch);
+                        idx.push_back(j);
+                        bt.push_back(d.sequence.tokens.back().id);
+                        bp.push_back(n_past);
+                        bs.push_back(j);
+                    }
+                    decode(c, bt.data(), bp.data(), bs.data(), (int)bt.size(), rows.data(), (int)rows.size());
+                    process_and_sample(c, params, t_cur, idx, rows, n_draw, fds > 0);
+                }
+            }
+            {
+                double best_score = -INFINITY;
+                for (int j = 0; j < n_decoders_cur; ++j) {
+                    Decoder &d = c.decoders[j];
+                    if (d.failed) continue;
+                    d.sequence.tokens.resize(d.sequence.result_len);
+                    sequence_score(params, d.sequence);
+                    if (d.sequence.result_len > 32 && d.sequence.entropy < params.entropy_thold) {
+                        d.failed = true;
+                        continue;
+                    }
+                    if (best_score < d.sequence.score) {
+                        best_score = d.sequence.score;
+                        best_decoder_id = j;
+                    }
+                }
+            }
+            bool success = true;
+            if (it != (int)temperatures.size() - 1) {
+                const Decoder &d = c.decoders[best_decoder_id];
+                if (d.failed || d.sequence.avg_logprobs < params.logprob_thold) success = false;
+            }
+            if (success) break;
+        }
+        {
+            const Decoder &best = c.decoders[best_decoder_id];
+            const int seek_delta = best.seek_delta;
+            const int result_len = best.sequence.result_len;
+            const auto &tokens_cur = best.sequence.tokens;
+            prompt_past.clear();
+            if (!prompt.empty() && prompt.front() == vocab.prev)
+                prompt_past.insert(prompt_past.end(), prompt.begin() + 1, prompt.end() - prompt_init.size());
+            for (int i = 0; i < result_len && i < (int)tokens_cur.size(); ++i) prompt_past.push_back(tokens_cur[i].id);
+            if (!tokens_cur.empty()) {
+                int i0 = 0;
+                int64_t t0 = seek + 2 * (tokens_cur.front().tid - vocab.beg);
+                std::string text;
+                for (int i = 0; i < (int)tokens_cur.size(); ++i) {
+                    if (params.print_special || tokens_cur[i].id < vocab.eot) text += vocab.id_to_token[tokens_cur[i].id];
+                    if (tokens_cur[i].id > vocab.beg && !params.single_segment) {
+                        const int64_t t1 = seek + 2 * (tokens_cur[i].tid - vocab.beg);
+                        if (!text.empty()) {
+                            result_all.push_back({t0, t1, text, {}});
+                            for (int j = i0; j <= i; ++j) result_all.back().tokens.push_back(tokens_cur[j]);
+                            if (params.new_segment_callback)
+                                params.new_segment_callback(nullptr, nullptr, 1, params.new_segment_callback_user_data);
+                        }
+                        text = "";
+                        while (i < (int)tokens_cur.size() && tokens_cur[i].id > vocab.beg) i++;
+                        i--;
+                        t0 = t1;
+                        i0 = i + 1;
+                    }
+                }
+                if (!text.empty()) {
+                    const int64_t t1 = seek + seek_delta;
+                    result_all.push_back({t0, t1, text, {}});
+                    for (int j = i0; j < (int)tokens_cur.size(); ++j) result_all.back().tokens.push_back(tokens_cur[j]);
+                    if (params.new_segment_callback)
+                        params.new_segment_callback(nullptr, nullptr, 1, params.new_segment_callback_user_data);
+                }
+            }
+            seek += seek_delta;
+        }
+    }
+    c.tm.total_ms += now_ms() - t_start;
+    return 0;
+}
+
+}  // namespace mw

@@ -1,0 +1,109 @@
+// engine.hpp — the whisper_context of the MI355X engine: model + per-context state + driver.
+#pragma once
+
+#include "model.hpp"
+
+#include "../../include/whisper.h"
+
+#include <memory>
+#include <random>
+#include <string>
+#include <vector>
+
+namespace mw {
+
+constexpr int MAX_DECODERS = KV_SLOTS;  // WHISPER_MAX_DECODERS
+constexpr int LOGIT_ROWS = 32;          // logits rows kept per decode call
+
+struct Sequence {
+    std::vector<whisper_token_data> tokens;
+    int result_len = 0;
+    double sum_logprobs_all = 0, sum_logprobs = 0, avg_logprobs = 0, entropy = 0, score = 0;
+};
+
+struct Decoder {
+    Sequence sequence;
+    int seek_delta = 0;
+    bool failed = false, completed = false, has_ts = false;
+    int i_batch = 0;
+    std::mt19937 rng;
+    // what the device sampler returned for this decoder's next token(s)
+    LogitsRowResult sampled;
+};
+
+struct Segment {
+    int64_t t0, t1;
+    std::string text;
+    std::vector<whisper_token_data> tokens;
+};
+
+struct Timings {
+    double mel_ms = 0, encode_ms = 0, decode_ms = 0, sample_ms = 0, total_ms = 0;
+    int n_encode = 0, n_decode = 0, n_sample = 0;
+};
+
+struct Context {
+    int device = 0;
+    hipStream_t st = nullptr;
+    Model model;
+    // ---- mel state ----
+    int n_len = 0, n_len_org = 0;
+    size_t pcm_cap = 0, mel_cap_frames = 0;
+    float *d_pcm = nullptr, *d_mel_raw = nullptr, *d_mel = nullptr;
+    unsigned *d_gmax = nullptr;
+    // ---- encoder workspace ----
+    int n_ctx_cur = 0;  // audio context of the last encode
+    int tp = 0;         // padded key count of the unfused attention path
+    void *d_conv_in = nullptr, *d_x1 = nullptr, *d_h = nullptr, *d_qk = nullptr, *d_vt = nullptr, *d_p = nullptr,
+         *d_att = nullptr, *d_ff = nullptr, *d_enc_out = nullptr;
+    float *d_x = nullptr, *d_s = nullptr;
+    void *d_cross = nullptr;  // [L][2][n_audio_ctx][d]
+    // ---- decoder workspace ----
+    void *d_kself = nullptr, *d_vself = nullptr;  // [L][KV_SLOTS][n_text_ctx][d]
+    int *d_kv_idx[2] = {nullptr, nullptr};
+    int kv_cur = 0;
+    int *d_tokens = nullptr, *d_pos = nullptr, *d_slot = nullptr, *d_rows = nullptr;
+    float *d_xd = nullptr, *d_q = nullptr, *d_attd = nullptr, *d_ffd = nullptr, *d_part = nullptr, *d_logits = nullptr,
+          *d_work = nullptr;
+    unsigned char *d_suppress = nullptr;
+    LogitsRowState *d_row_state = nullptr;
+    LogitsRowResult *d_row_res = nullptr;
+    // pinned host staging
+    int *h_ints = nullptr;  // tokens | pos | slot | rows
+    LogitsRowState *h_row_state = nullptr;
+    LogitsRowResult *h_row_res = nullptr;
+    int n_logit_rows = 0;
+    // ---- whisper_full state ----
+    Decoder decoders[MAX_DECODERS];
+    std::vector<Segment> result_all;
+    std::vector<int> prompt_past;
+    int lang_id = 0;
+    int exp_n_audio_ctx = 0;
+    int force_decode_steps = 0;  // bench-only extension (mw_set_force_decode_steps)
+    std::string suppress_key;    // cache key of the uploaded suppression mask
+    Timings tm;
+
+    ~Context();
+};
+
+// throws on failure
+std::unique_ptr<Context> create_context(const unsigned char *data, size_t size, int device, DType wt);
+
+// stage entry points (used by whisper_full and by the parity API)
+void pcm_to_mel(Context &c, const float *pcm, int n_samples, bool pcm_on_device);
+void encode(Context &c, int seek);
+// decode n tokens; logits are produced for the rows listed in logit_rows (indices into the batch)
+void decode(Context &c, const int *tokens, const int *pos, const int *slot, int n, const int *logit_rows, int n_logit_rows);
+void kv_clear(Context &c);
+void kv_reorder(Context &c, const int *src /*[MAX_DECODERS]*/, int n_past);
+int lang_auto_detect(Context &c, int offset_ms, float *probs);
+int full(Context &c, whisper_full_params params, const float *samples, int n_samples);
+// builds + uploads the static suppression mask for these params (cached)
+void upload_suppress_mask(Context &c, const whisper_full_params &params);
+LogitsParams make_logits_params(const Context &c, const whisper_full_params &params, float temperature, int n_samples);
+
+}  // namespace mw
+
+struct whisper_context {
+    std::unique_ptr<mw::Context> c;
+};

@@ -1,0 +1,236 @@
+// gemm.hip — K2/K4/K5(unfused)/K6: LDS-tiled MFMA GEMM for gfx950, "NT" form
+//     C[m][n] = act(alpha * sum_k A[m][k] * W[n][k] + bias[n]) + R[m][n]
+// Both operands are K-contiguous (activations [rows][features], weights as stored in the GGML file
+// [out][in]), so A and B fragments are the same 16-byte K-runs.  Used for the conv stem (the stem is a
+// GEMM over a strided VIEW of the frame-major mel / conv1 output: row t = rows t-1,t,t+1 concatenated),
+// the encoder projections and MLP, QK^T / PV of the unfused attention path, and the cross-K/V
+// precompute.  Replaces the ggml mul_mat / conv_1d graph nodes whisper.cpp runs inside whisper_full
+// (/root/reference/src/whisper-utils/whisper-processing.cpp:218-219).
+//
+// Bound: MFMA.  bf16 path: 128x128x32 tile, 4 waves (2x2), each wave 4x4 tiles of
+// v_mfma_f32_16x16x32_bf16, operands staged global -> registers -> LDS (XOR-swizzled 64-byte rows so
+// ds_read_b128 fragment reads are conflict-free), double-buffered so the next tile's global loads are
+// in flight during the MFMAs.  fp32 path (bit-exact-token mode for tiny/base): same tiling on
+// v_mfma_f32_32x32x2_f32 (exact fp32 fma chain), LDS tile stored k-major.
+#include "kernels.hpp"
+
+#include <hip/hip_bf16.h>
+
+namespace mw {
+
+namespace {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) short;   // 8 bf16 = 4 VGPRs (MFMA A/B fragment)
+using bf16x8b = __attribute__((ext_vector_type(8))) __bf16;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int BM = 128, BN = 128;
+constexpr int ROW_BYTES = 64;  // K-extent of one LDS tile row: 32 bf16 or 16 f32
+constexpr int F32_LD = BM + 4; // k-major f32 tile: row length (floats) incl. padding
+
+__device__ __forceinline__ float gelu_f(float x) {
+    const float c = 0.79788456080286535587989211986876f, a = 0.044715f;
+    return 0.5f * x * (1.0f + tanhf(c * x * (1.0f + a * x * x)));
+}
+
+__device__ __forceinline__ void store_out(float *p, float v) { *p = v; }
+__device__ __forceinline__ void store_out(bf16_t *p, float v) {
+    __hip_bfloat16 h = __float2bfloat16(v);
+    *p = *reinterpret_cast<bf16_t *>(&h);
+}
+
+// swizzled byte offset of 16-byte chunk c (0..3) of tile row r (64-byte rows)
+__device__ __forceinline__ int swz(int r, int c) {
+    const int g = (0x1320 >> (((r >> 2) & 3) * 4)) & 3;  // g = [0,2,3,1][(r>>2)&3]
+    return r * ROW_BYTES + ((c ^ g) << 4);
+}
+
+template <typename TIN, typename TOUT>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
+    constexpr bool F32 = sizeof(TIN) == 4;
+    constexpr int BK = ROW_BYTES / (int)sizeof(TIN);
+    // LDS: [2 buffers][A | W]; bf16: 128 rows x 64 B swizzled; f32: 16 k-rows x F32_LD floats
+    constexpr int TILE_BYTES = F32 ? 16 * F32_LD * 4 : BM * ROW_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * TILE_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int z0 = blockIdx.z / a.nz1, z1 = blockIdx.z % a.nz1;
+    const TIN *A = (const TIN *)a.A + z0 * a.sA0 + z1 * a.sA1;
+    const TIN *W = (const TIN *)a.W + z0 * a.sW0 + z1 * a.sW1;
+    TOUT *C = (TOUT *)a.C + z0 * a.sC0 + z1 * a.sC1;
+    const float *bias = a.bias ? a.bias + z0 * a.sB0 + z1 * a.sB1 : nullptr;
+    const float *R = a.R ? a.R + z0 * a.sR0 + z1 * a.sR1 : nullptr;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int M = a.M, N = a.N, K = a.K;
+
+    // this thread's two 16-byte chunks per operand tile: idx = tid + 256 q -> row idx>>2, chunk idx&3
+    int lrow[2], lchk[2];
+    const TIN *ga[2], *gw[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int idx = tid + 256 * q;
+        lrow[q] = idx >> 2;
+        lchk[q] = idx & 3;
+        const int ra = min(m0 + lrow[q], M - 1), rw = min(n0 + lrow[q], N - 1);
+        ga[q] = A + (long)ra * a.lda + lchk[q] * (16 / (int)sizeof(TIN));
+        gw[q] = W + (long)rw * a.ldw + lchk[q] * (16 / (int)sizeof(TIN));
+    }
+    const int nk = (K + BK - 1) / BK;
+    uint4 ra_[2], rw_[2];
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int kk = kt * BK + lchk[q] * (16 / (int)sizeof(TIN));
+            if (kk < K) {
+                ra_[q] = *reinterpret_cast<const uint4 *>(ga[q] + (long)kt * BK);
+                rw_[q] = *reinterpret_cast<const uint4 *>(gw[q] + (long)kt * BK);
+            } else {
+                ra_[q] = make_uint4(0, 0, 0, 0);
+                rw_[q] = make_uint4(0, 0, 0, 0);
+            }
+        }
+    };
+    auto lstore = [&](int buf) {
+        unsigned char *la = lds + buf * 2 * TILE_BYTES, *lw = la + TILE_BYTES;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if constexpr (F32) {
+                float *fa = (float *)la, *fw = (float *)lw;
+                const int kb = lchk[q] * 4;
+                fa[(kb + 0) * F32_LD + lrow[q]] = __uint_as_float(ra_[q].x);
+                fa[(kb + 1) * F32_LD + lrow[q]] = __uint_as_float(ra_[q].y);
+                fa[(kb + 2) * F32_LD + lrow[q]] = __uint_as_float(ra_[q].z);
+                fa[(kb + 3) * F32_LD + lrow[q]] = __uint_as_float(ra_[q].w);
+                fw[(kb + 0) * F32_LD + lrow[q]] = __uint_as_float(rw_[q].x);
+                fw[(kb + 1) * F32_LD + lrow[q]] = __uint_as_float(rw_[q].y);
+                fw[(kb + 2) * F32_LD + lrow[q]] = __uint_as_float(rw_[q].z);
+                fw[(kb + 3) * F32_LD + lrow[q]] = __uint_as_float(rw_[q].w);
+            } else {
+                *reinterpret_cast<uint4 *>(la + swz(lrow[q], lchk[q])) = ra_[q];
+                *reinterpret_cast<uint4 *>(lw + swz(lrow[q], lchk[q])) = rw_[q];
+            }
+        }
+    };
+
+    // accumulators: bf16 path 4x4 tiles of 16x16 (f32x4); fp32 path 2x2 tiles of 32x32 (f32x16)
+    f32x4 acc16[F32 ? 1 : 4][F32 ? 1 : 4];
+    f32x16 acc32[F32 ? 2 : 1][F32 ? 2 : 1];
+    if constexpr (F32) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc32[i][j][r] = 0.0f;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc16[i][j] = f32x4{0, 0, 0, 0};
+    }
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);
+        const unsigned char *la = lds + cur * 2 * TILE_BYTES, *lw = la + TILE_BYTES;
+        if constexpr (F32) {
+            const float *fa = (const float *)la, *fw = (const float *)lw;
+            const int li = lane & 31, lk = lane >> 5;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                float av[2], bv[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    av[i] = fa[(ks * 2 + lk) * F32_LD + wr * 64 + i * 32 + li];
+                    bv[i] = fw[(ks * 2 + lk) * F32_LD + wc * 64 + i * 32 + li];
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc32[i][j], 0, 0, 0);
+            }
+        } else {
+            const int fr = lane & 15, fq = lane >> 4;
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = *reinterpret_cast<const bf16x8 *>(la + swz(wr * 64 + i * 16 + fr, fq));
+                bfr[i] = *reinterpret_cast<const bf16x8 *>(lw + swz(wc * 64 + i * 16 + fr, fq));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8b, af[i]), __builtin_bit_cast(bf16x8b, bfr[j]), acc16[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            lstore(cur ^ 1);  // the other buffer was last read before the previous barrier
+            __syncthreads();
+        }
+    }
+
+    // epilogue
+    auto emit = [&](int m, int n, float v) {
+        if (m >= M || n >= N) return;
+        v *= a.alpha;
+        if (bias) v += bias[n];
+        if (a.act == ACT_GELU) v = gelu_f(v);
+        if (R) v += R[(long)m * a.ldr + n];
+        if (a.trans_c) store_out(C + (long)n * a.ldc + m, v);
+        else store_out(C + (long)m * a.ldc + n, v);
+    };
+    if constexpr (F32) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    emit(m0 + wr * 64 + i * 32 + row, n0 + wc * 64 + j * 32 + (lane & 31), acc32[i][j][r]);
+                }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    emit(m0 + wr * 64 + i * 16 + (lane >> 4) * 4 + r, n0 + wc * 64 + j * 16 + (lane & 15), acc16[i][j][r]);
+    }
+}
+
+}  // namespace
+
+void launch_gemm(const GemmArgs &a, DType in, DType out, hipStream_t st) {
+    MW_CHECK(a.A && a.W && a.C, "gemm: null operand");
+    MW_CHECK(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty shape");
+    const int epc = in == DType::F32 ? 4 : 8;  // elements per 16-byte chunk
+    MW_CHECK(a.K % epc == 0, "gemm: K must be a multiple of the 16-byte chunk");
+    MW_CHECK(a.lda % epc == 0 && a.ldw % epc == 0, "gemm: row strides must keep 16-byte alignment");
+    MW_CHECK(((uintptr_t)a.A % 16) == 0 && ((uintptr_t)a.W % 16) == 0, "gemm: operands must be 16-byte aligned");
+    MW_CHECK(a.sA0 % epc == 0 && a.sA1 % epc == 0 && a.sW0 % epc == 0 && a.sW1 % epc == 0, "gemm: batch strides");
+    // note: lda < K is legal — the conv stem passes overlapping row views (row t = rows t-1..t+1)
+    MW_CHECK(a.nz0 >= 1 && a.nz1 >= 1 && (long)a.nz0 * a.nz1 <= 65535, "gemm: batch count");
+    if (a.R) MW_CHECK(a.ldr > 0, "gemm: residual stride");
+    dim3 grid(ceil_div(a.N, BN), ceil_div(a.M, BM), a.nz0 * a.nz1);
+    MW_CHECK(grid.y <= 65535, "gemm: M too large for grid.y");
+    if (in == DType::F32 && out == DType::F32)
+        hipLaunchKernelGGL((gemm_nt_kernel<float, float>), grid, dim3(256), 0, st, a);
+    else if (in == DType::BF16 && out == DType::F32)
+        hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, float>), grid, dim3(256), 0, st, a);
+    else if (in == DType::BF16 && out == DType::BF16)
+        hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, st, a);
+    else
+        MW_CHECK(false, "gemm: unsupported dtype combination");
+    MW_HIP(hipGetLastError());
+}
+
+}  // namespace mw

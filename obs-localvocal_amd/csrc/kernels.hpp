@@ -1,0 +1,159 @@
+// kernels.hpp — host-side launchers of the hand-written gfx950 kernels (definitions in *.hip).
+// Every launcher validates the shapes its kernel and grid assume before launching.
+#pragma once
+
+#include "common.hpp"
+
+#include <algorithm>
+
+namespace mw {
+
+// ------------------------------------------------------------------------------------------
+// K1 log-mel (mel.hip)
+// ------------------------------------------------------------------------------------------
+constexpr int MEL_MAX_BINS = 128;
+constexpr int MEL_N_FFT = 400;
+constexpr int MEL_HOP = 160;
+constexpr int MEL_N_FREQ = 201;
+constexpr int MEL_MAX_VALS = 2048;  // packed filter taps (groups of 4, zero-padded)
+
+// Filter bank + trig tables as the kernel consumes them (built once per model on the host).
+struct MelTables {
+    float tw_cos[MEL_N_FFT];
+    float tw_sin[MEL_N_FFT];
+    float hann[MEL_N_FFT];
+    int n_mel;
+    int k0[MEL_MAX_BINS];      // first frequency bin of the bin's first tap group (multiple of 4)
+    int ngrp[MEL_MAX_BINS];    // number of 4-tap groups
+    int voff[MEL_MAX_BINS];    // offset of the bin's taps in vals[]
+    float last[MEL_MAX_BINS];  // tap at the Nyquist bin (k = 200), summed separately like the reference
+    float vals[MEL_MAX_VALS];
+};
+
+// raw[s][frame][bin] = log10(max(mel power, 1e-10)) for frame < n_active, gmax[s] = ordered-int max
+void launch_mel_frames(const float *d_pcm, long pcm_stride, int n_samples, int n_streams, const MelTables *d_tab,
+                       float *d_raw, long raw_stride, int n_active, int n_mel, unsigned *d_gmax, hipStream_t st);
+// out[s][frame][bin] = (max(raw, gmax-8) + 4)/4 for frame < n_active, the clamped floor value beyond
+void launch_mel_normalize(const float *d_raw, long raw_stride, float *d_out, long out_stride, int n_len, int n_active,
+                          int n_mel, int n_streams, const unsigned *d_gmax, hipStream_t st);
+// conv-stem operand: dst[s][1 + i][bin] = mel[s][seek + i][bin] (0 beyond n_len), rows 0 and n_rows+1 zero
+void launch_mel_window(const float *d_mel, long mel_stride, int n_len, int seek, int n_rows, int n_mel, int n_streams,
+                       void *d_dst, long dst_stride, DType dt, hipStream_t st);
+// whisper layout for the getter: out[bin][frame] <- in[frame][bin]
+void launch_transpose_f32(const float *d_in, float *d_out, int rows, int cols, hipStream_t st);
+
+// ------------------------------------------------------------------------------------------
+// K2/K4/K6 GEMM  C[m][n] = act(alpha * sum_k A[m][k] W[n][k] + bias[n]) + R[m][n]   (gemm.hip)
+// ------------------------------------------------------------------------------------------
+enum { ACT_NONE = 0, ACT_GELU = 1 };
+
+struct GemmArgs {
+    const void *A = nullptr;  // [M][K], row stride lda (elements)
+    const void *W = nullptr;  // [N][K], row stride ldw
+    void *C = nullptr;        // [M][N] (or [N][M] when trans_c), row stride ldc
+    const float *bias = nullptr;
+    const float *R = nullptr;  // residual (f32), row stride ldr; may alias C when C is f32
+    long lda = 0, ldw = 0, ldc = 0, ldr = 0;
+    int M = 0, N = 0, K = 0;
+    // batching: blockIdx.z = z0 * nz1 + z1
+    int nz0 = 1, nz1 = 1;
+    long sA0 = 0, sA1 = 0, sW0 = 0, sW1 = 0, sC0 = 0, sC1 = 0, sB0 = 0, sB1 = 0, sR0 = 0, sR1 = 0;
+    float alpha = 1.0f;
+    int act = ACT_NONE;
+    int trans_c = 0;
+};
+// in: element type of A and W; out: element type of C
+void launch_gemm(const GemmArgs &a, DType in, DType out, hipStream_t st);
+
+// ------------------------------------------------------------------------------------------
+// K3 LayerNorm, softmax, misc (enc_misc.hip)
+// ------------------------------------------------------------------------------------------
+void launch_layernorm(const float *x, long ldx, const float *w, const float *b, void *out, long ldo, DType out_t,
+                      int rows, int d, hipStream_t st);
+// rows x n scaled softmax of f32 scores, written as out_t with columns [n, n_pad) zeroed
+void launch_softmax_rows(const float *s, long lds_, void *out, long ldo, DType out_t, long rows, int n, int n_pad,
+                         float scale, hipStream_t st);
+void launch_fill_zero(void *p, size_t bytes, hipStream_t st);
+void launch_convert(const float *src, void *dst, DType dt, size_t n, hipStream_t st);
+
+// ------------------------------------------------------------------------------------------
+// K7/K8 decoder step (dec.hip)
+// ------------------------------------------------------------------------------------------
+constexpr int DEC_MAX_ROWS = 8;      // activation rows one weight pass serves
+constexpr int KV_SLOTS = 8;          // physical self-KV slots per stream (= WHISPER_MAX_DECODERS)
+constexpr int CROSS_SPLITS_MAX = 16;
+
+// x[i][:] = tok_emb[token[i]][:] + pos_emb[pos[i]][:]
+void launch_embed(const int *d_tokens, const int *d_pos, const void *tok_emb, DType wt, const float *pos_emb,
+                  float *x, int n, int d, hipStream_t st);
+
+struct GemvArgs {
+    const float *x = nullptr;  // [n][K] f32 activations (row stride ldx)
+    long ldx = 0;
+    int n = 0;                 // rows (any count; processed DEC_MAX_ROWS at a time)
+    const void *W = nullptr;   // [N][K]
+    const float *bias = nullptr;
+    int N = 0, K = 0;
+    const float *ln_w = nullptr, *ln_b = nullptr;  // when set: LayerNorm(x) is applied first
+    int act = ACT_NONE;
+    float out_scale = 1.0f;    // applied to (x W^T + b) before the activation
+    float *out = nullptr;      // [n][N] f32 (row stride ldo); out = (R ? R : 0) + act(out_scale * (x W^T + b))
+    long ldo = 0;
+    const float *R = nullptr;  // residual, same layout as out (may alias out)
+    // fused self-attention projection epilogue (N = 3d): columns [0,d) -> out (scaled by qk_scale),
+    // [d,2d) -> K cache (scaled), [2d,3d) -> V cache, at (slot[i], pos[i])
+    int qkv = 0;
+    float qk_scale = 1.0f;
+    void *kcache = nullptr, *vcache = nullptr;  // [KV_SLOTS][n_text_ctx][d] of this layer
+    DType kv_t = DType::BF16;
+    const int *d_slot = nullptr, *d_pos = nullptr;
+    int n_text_ctx = 0;
+    const int *d_rows = nullptr;  // optional row gather: use x row d_rows[i] for output row i
+};
+void launch_gemv(const GemvArgs &a, DType wt, hipStream_t st);
+
+// self-attention of n query rows over the indirected cache: row i attends positions 0..pos[i] of
+// logical sequence slot[i]; position p of sequence s lives in physical slot kv_idx[s][p].
+void launch_self_attn(const float *q, const void *kcache, const void *vcache, DType kv_t, const int *d_slot,
+                      const int *d_pos, const int *d_kv_idx, float *out, int n, int H, int d, int n_text_ctx,
+                      hipStream_t st);
+// cross-attention of n query rows over the stream's encoder K/V [n_ctx][d]; split over keys
+void launch_cross_attn(const float *q, const void *kc, const void *vc, DType kv_t, float *partial, float *out, int n,
+                       int H, int d, int n_ctx, int splits, hipStream_t st);
+// new_idx[j][p] = old_idx[src[j]][p] for p < n_past; new_idx[j][n_past] = j   (beam reshuffle)
+struct BeamSrc {
+    int src[KV_SLOTS];
+};
+void launch_kv_reorder(const int *old_idx, int *new_idx, BeamSrc src, int n_past, int n_text_ctx, hipStream_t st);
+
+// ------------------------------------------------------------------------------------------
+// K9/K10 logits rules + samplers (logits.hip)
+// ------------------------------------------------------------------------------------------
+constexpr int MAX_CAND = 8;
+
+struct LogitsParams {
+    int n_vocab, eot, beg, space_id;
+    int suppress_blank;
+    float temperature;
+    int tid0_initial;  // round(max_initial_ts / 0.02), <0: rule disabled
+    int n_samples;     // 0: greedy argmax ("best"); k>0: draw k samples from the distribution
+};
+struct LogitsRowState {   // per decoder row, uploaded per step
+    int logits_row;       // row of the logits matrix
+    int n_sampled;        // tokens sampled so far (0 => initial)
+    int last_is_ts, penult_is_ts;
+    int has_ts, seek_delta;
+    double u[MAX_CAND];   // uniform draws for the samplers
+};
+struct LogitsRowResult {
+    int tid;
+    float pt, ptsum;
+    int id[MAX_CAND];
+    float p[MAX_CAND], plog[MAX_CAND];
+};
+// suppress: per-token byte mask (1 = always suppressed).  Optional full-row dumps for parity tests.
+void launch_process_logits(const float *logits, long ld, const unsigned char *suppress, const LogitsParams &p,
+                           const LogitsRowState *d_rows, LogitsRowResult *d_res, int n_rows, float *work,
+                           float *dump_logits, float *dump_logprobs, float *dump_probs, hipStream_t st);
+
+}  // namespace mw

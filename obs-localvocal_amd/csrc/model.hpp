@@ -1,0 +1,105 @@
+// model.hpp — GGML-legacy Whisper model files -> HBM-resident weights (K13).
+//
+// Replaces the model loading whisper.cpp does inside whisper_init_from_file_with_params /
+// whisper_init_from_buffer_with_params, called from init_whisper_context
+// (/root/reference/src/whisper-utils/whisper-processing.cpp:109,112).  The file is parsed once; every
+// tensor is converted to the engine's compute type (bf16, or fp32 in exact mode), re-laid out where a
+// kernel wants it (Q|K|V rows concatenated, conv taps k-major, cross K|V of all layers contiguous)
+// and uploaded into one device arena.  File layout: SURVEY.md Appendix A.1.
+#pragma once
+
+#include "kernels.hpp"
+
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace mw {
+
+struct HParams {
+    int n_vocab = 0, n_audio_ctx = 0, n_audio_state = 0, n_audio_head = 0, n_audio_layer = 0;
+    int n_text_ctx = 0, n_text_state = 0, n_text_head = 0, n_text_layer = 0, n_mels = 0, ftype = 0;
+};
+
+struct Vocab {
+    int n_vocab = 0;
+    std::vector<std::string> id_to_token;
+    std::unordered_map<std::string, int> token_to_id;
+    int eot = 50256, sot = 50257, translate = 50357, transcribe = 50358, solm = 50359, prev = 50360, nosp = 50361,
+        not_ = 50362, beg = 50363;
+    bool is_multilingual() const { return n_vocab >= 51865; }
+    int num_languages() const { return n_vocab - 51765 - (is_multilingual() ? 1 : 0); }
+    int lang_token(int lang_id) const { return sot + 1 + lang_id; }
+    std::vector<int> tokenize(const std::string &text) const;
+};
+
+constexpr int N_LANGS = 100;
+const char *lang_str(int id);  // nullptr when out of range
+int lang_id(const char *code); // -1 when unknown
+
+struct EncLayer {
+    float *ln1_w, *ln1_b, *ln2_w, *ln2_b;
+    void *qk_w;   // [2d][d]  (query rows, then key rows)
+    float *qk_b;  // [2d]     (key half zero: whisper has no key bias)
+    void *v_w;
+    float *v_b;
+    void *out_w;
+    float *out_b;
+    void *fc1_w;
+    float *fc1_b;
+    void *fc2_w;
+    float *fc2_b;
+};
+
+struct DecLayer {
+    float *ln1_w, *ln1_b, *lnc_w, *lnc_b, *ln2_w, *ln2_b;
+    void *qkv_w;   // [3d][d]
+    float *qkv_b;  // [3d] (key third zero)
+    void *out_w;
+    float *out_b;
+    void *cq_w;
+    float *cq_b;
+    void *co_w;
+    float *co_b;
+    void *fc1_w;
+    float *fc1_b;
+    void *fc2_w;
+    float *fc2_b;
+};
+
+struct Model {
+    HParams hp;
+    Vocab vocab;
+    DType wt = DType::BF16;  // element type of matrix weights, activations fed to MFMA, and KV caches
+    std::vector<float> mel_filters;  // host copy [n_mel][201]
+    MelTables *d_mel_tab = nullptr;
+    void *conv1_w = nullptr;  // [d][3*n_mel], tap-major: column = k*n_mel + c_in
+    float *conv1_b = nullptr;
+    void *conv2_w = nullptr;  // [d][3*d]
+    float *conv2_b = nullptr;
+    float *enc_pe = nullptr;  // [n_audio_ctx][d] f32
+    std::vector<EncLayer> enc;
+    float *ln_post_w = nullptr, *ln_post_b = nullptr;
+    float *dec_pe = nullptr;   // [n_text_ctx][d] f32
+    void *tok_emb = nullptr;   // [n_vocab][d]
+    std::vector<DecLayer> dec;
+    void *ckv_w = nullptr;   // [L][2][d][d]  cross-attention key | value weights of every decoder layer
+    float *ckv_b = nullptr;  // [L][2][d]     (key halves zero)
+    float *dec_ln_w = nullptr, *dec_ln_b = nullptr;
+    // device arena
+    char *arena = nullptr;
+    size_t arena_size = 0, arena_used = 0;
+    size_t n_params = 0;
+
+    ~Model();
+    Model() = default;
+    Model(const Model &) = delete;
+    Model &operator=(const Model &) = delete;
+};
+
+// Parses `size` bytes at `data` (a whole ggml-*.bin image) and uploads to the current HIP device.
+// Throws std::runtime_error on malformed input.
+void load_model(Model &m, const unsigned char *data, size_t size, DType wt, hipStream_t st);
+
+}  // namespace mw

@@ -35,3 +35,21 @@ def model_file(model_dir):
         return cache[key]
 
     return get
+
+
+def load_package():
+    """Import obs-localvocal_amd/ (hyphenated directory) as module `obs_localvocal_amd`."""
+    import importlib.util
+    if "obs_localvocal_amd" in sys.modules:
+        return sys.modules["obs_localvocal_amd"]
+    path = os.path.join(ROOT, "obs-localvocal_amd", "__init__.py")
+    spec = importlib.util.spec_from_file_location("obs_localvocal_amd", path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["obs_localvocal_amd"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    return load_package()

@@ -1,0 +1,489 @@
+"""GPU parity tests proper: every stage of the hot path, called through the C ABI
+(libmi355_whisper.so), against the CPU oracle on the same seeded inputs.
+
+Bars (north_star): mel <= 1e-4; fp32 mode: logits ~1e-3 abs and greedy tokens bit-exact;
+bf16 mode: encoder activations / logits within the stated bf16 tolerance, token match rate reported.
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle
+from tools import ggml_io
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def engines(pkg, model_file):
+    cache = {}
+
+    def get(preset, precision):
+        key = (preset, precision)
+        if key not in cache:
+            cache[key] = pkg.Engine(model_file(preset), precision=precision)
+        return cache[key]
+
+    yield get
+    for e in cache.values():
+        e.close()
+
+
+@pytest.fixture(scope="module")
+def oracles(model_file):
+    cache = {}
+
+    def get(preset):
+        if preset not in cache:
+            cache[preset] = pyoracle.Oracle(model_file(preset))
+        return cache[preset]
+
+    return get
+
+
+# ---------------------------------------------------------------------------------------------
+# K1 mel
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("preset", ["micro.en", "micro"])
+@pytest.mark.parametrize("seed,secs", [(0, 30.0), (1, 3.0), (2, 0.9), (3, 1.01), (4, 11.02)])
+def test_mel_matches_oracle(pkg, engines, oracles, preset, seed, secs):
+    eng, orc = engines(preset, pkg.PRECISION_FP32), oracles(preset)
+    pcm = ggml_io.synth_pcm(seed, secs)
+    ref = orc.mel(pcm)
+    got = eng.mel(pcm)
+    assert got.shape == ref.shape
+    err = np.abs(got - ref).max()
+    assert err < 1e-4, err  # north_star: mel within 1e-4 (values are O(1))
+
+
+def test_mel_edge_inputs(pkg, engines, oracles):
+    eng, orc = engines("micro.en", pkg.PRECISION_FP32), oracles("micro.en")
+    for pcm in (np.zeros(16000, np.float32),                      # silence: everything at the clamp floor
+                np.ones(1, np.float32),                           # a single sample
+                np.r_[np.zeros(300, np.float32), 1.0, np.zeros(400, np.float32)].astype(np.float32),  # click
+                ggml_io.synth_pcm(5, 0.3) * 30.0):                # loud, shorter than one reflect pad + frame
+        ref, got = orc.mel(pcm), eng.mel(pcm)
+        assert got.shape == ref.shape and np.abs(got - ref).max() < 1e-4
+
+
+def test_mel_matches_hf_golden(pkg, engines):
+    # the committed HF-derived vectors, directly (not via the oracle)
+    eng = engines("micro", pkg.PRECISION_FP32)
+    g = np.load(os.path.join(GOLD, "mel_128_seed0.npz"))
+    got = eng.mel(ggml_io.synth_pcm(0, 30.0))[:, :3000][:, ::int(g["stride"])]
+    fr = np.arange(0, 3000, int(g["stride"]))
+    inside = fr < (480000 - 200) // 160
+    assert np.abs(got[:, inside] - g["mel"][:, inside]).max() < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------
+# K2-K6 encoder + cross-KV
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("preset", ["micro.en", "micro"])
+def test_encoder_fp32_matches_oracle(pkg, engines, oracles, preset):
+    eng, orc = engines(preset, pkg.PRECISION_FP32), oracles(preset)
+    pcm = ggml_io.synth_pcm(0, 30.0)
+    orc.mel(pcm)
+    eng.mel(pcm)
+    ref, got = orc.encode(0), eng.encode(0)
+    assert np.abs(got - ref).max() < 2e-3  # fp32 both sides, different summation order
+    for layer in range(orc.n_text_layer):
+        for is_v in (False, True):
+            assert np.abs(eng.cross_kv(layer, is_v) - orc.cross_kv(layer, is_v)).max() < 2e-3
+    # a window that starts late in the clip (zero-filled beyond the mel) and a reduced audio context
+    ref, got = orc.encode(2900), eng.encode(2900)
+    assert np.abs(got - ref).max() < 2e-3
+    ref, got = orc.encode(0, 512), eng.encode(0, 512)
+    assert got.shape == (512, orc.n_audio_state) and np.abs(got - ref).max() < 2e-3
+
+
+def test_encoder_matches_hf_golden(pkg, engines):
+    eng = engines("micro.en", pkg.PRECISION_FP32)
+    g = np.load(os.path.join(GOLD, "encdec_micro.en.npz"))
+    eng.mel(ggml_io.synth_pcm(0, 30.0))
+    enc = eng.encode(0)
+    assert np.abs(enc[::25][:-1] - g["enc_rows"][:-1]).max() < 2e-3
+    logits = eng.decode(g["tokens"], 0, 0)
+    assert np.abs(logits[:, g["cols"]] - g["logits"]).max() < 2e-3
+    assert (logits.argmax(-1) == g["argmax"]).all()
+
+
+@pytest.mark.parametrize("preset", ["micro.en", "micro"])
+def test_encoder_bf16_within_tolerance(pkg, engines, oracles, preset):
+    eng, orc = engines(preset, pkg.PRECISION_BF16), oracles(preset)
+    pcm = ggml_io.synth_pcm(0, 30.0)
+    orc.mel(pcm)
+    eng.mel(pcm)
+    ref, got = orc.encode(0), eng.encode(0)
+    # stated bf16 tolerance: post-LayerNorm activations are O(1); bf16 operands (8-bit mantissa)
+    # through 2 blocks give ~1e-2 absolute error, far below the activation scale
+    err = np.abs(got - ref)
+    assert err.max() < 0.08 and err.mean() < 0.01, (err.max(), err.mean())
+    rel = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+    assert rel < 0.01, rel
+
+
+# ---------------------------------------------------------------------------------------------
+# K7/K8 decoder
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("preset", ["micro.en", "micro"])
+def test_decoder_fp32_matches_oracle(pkg, engines, oracles, preset):
+    eng, orc = engines(preset, pkg.PRECISION_FP32), oracles(preset)
+    pcm = ggml_io.synth_pcm(1, 5.0)
+    orc.mel(pcm)
+    eng.mel(pcm)
+    orc.encode(0)
+    eng.encode(0)
+    rs = np.random.RandomState(3)
+    toks = [orc.sot] + [int(t) for t in rs.randint(0, 50000, size=19)]
+    ref = orc.decode(toks, 0, 0)
+    got = eng.decode(toks, 0, 0)   # 20-token prompt: exercises the >8-row chunking and causal attention
+    assert np.abs(got - ref).max() < 2e-3
+    assert (got.argmax(-1) == ref.argmax(-1)).all()
+    # incremental steps on another sequence, interleaved with sequence 0
+    orc.decode(toks[:3], 0, 2)
+    eng.decode(toks[:3], 0, 2)
+    for i in range(3, 12):
+        r = orc.decode(toks[i:i + 1], i, 2)[0]
+        g = eng.decode(toks[i:i + 1], i, 2)[0]
+        assert np.abs(g - r).max() < 2e-3 and np.abs(g - ref[i]).max() < 2e-3
+
+
+def test_decoder_bf16_within_tolerance(pkg, engines, oracles):
+    eng, orc = engines("micro.en", pkg.PRECISION_BF16), oracles("micro.en")
+    pcm = ggml_io.synth_pcm(1, 5.0)
+    orc.mel(pcm)
+    eng.mel(pcm)
+    orc.encode(0)
+    eng.encode(0)
+    toks = [orc.sot, 11, 22, 33, 44]
+    ref, got = orc.decode(toks, 0, 0), eng.decode(toks, 0, 0)
+    # logits are O(0.5) here; bf16 weights + bf16 KV: absolute error well under the top-2 logit gaps
+    assert np.abs(got - ref).max() < 0.05
+
+
+def test_decoder_full_context(pkg, engines, oracles):
+    # maximum sizes: a 224-token prompt and positions up to n_text_ctx - 1
+    eng, orc = engines("micro.en", pkg.PRECISION_FP32), oracles("micro.en")
+    pcm = ggml_io.synth_pcm(2, 2.0)
+    orc.mel(pcm)
+    eng.mel(pcm)
+    orc.encode(0)
+    eng.encode(0)
+    rs = np.random.RandomState(5)
+    toks = [int(t) for t in rs.randint(0, 50000, size=447)]
+    ref = orc.decode(toks, 0, 0)[-32:]
+    got = eng.decode(toks, 0, 0)
+    assert got.shape == ref.shape and np.abs(got - ref).max() < 3e-3
+    r = orc.decode([7], 447, 0)[0]
+    g = eng.decode([7], 447, 0)[0]
+    assert np.abs(g - r).max() < 3e-3
+    with pytest.raises(RuntimeError):
+        eng.decode([7], 448, 0)  # beyond n_text_ctx: rejected on the host, nothing launched
+
+
+# ---------------------------------------------------------------------------------------------
+# K9/K10 logits rules + samplers
+# ---------------------------------------------------------------------------------------------
+def _oracle_params(orc, p, **kw):
+    return orc.default_params(int(p.strategy), suppress_blank=int(p.suppress_blank),
+                              suppress_non_speech_tokens=int(p.suppress_non_speech_tokens),
+                              no_timestamps=int(p.no_timestamps), max_initial_ts=p.max_initial_ts, **kw)
+
+
+@pytest.mark.parametrize("preset", ["micro.en", "micro"])
+def test_process_logits_matches_oracle(pkg, engines, oracles, preset):
+    eng, orc = engines(preset, pkg.PRECISION_FP32), oracles(preset)
+    beg, nv = orc.beg, orc.n_vocab
+    cases = [
+        dict(hist=[], kw={}),
+        dict(hist=[], kw=dict(suppress_blank=False)),
+        dict(hist=[beg + 10, 500, 600], kw={}),
+        dict(hist=[beg + 10, 500, beg + 40], kw={}),
+        dict(hist=[beg + 10, 500, beg + 40, beg + 40], kw={}),
+        dict(hist=[700, 800], kw={}, boost_ts=True),
+        dict(hist=[beg + 5], kw={}),
+        dict(hist=[300], kw=dict(no_timestamps=True)),
+        dict(hist=[300, 400], kw=dict(suppress_non_speech_tokens=True), temp=0.4),
+        dict(hist=[], kw=dict(max_initial_ts=0.0)),
+    ]
+    for ci, cs in enumerate(cases):
+        rs = np.random.RandomState(2000 + ci)
+        logits = (rs.standard_normal(nv) * 3.0).astype(np.float32)
+        if cs.get("boost_ts"):
+            logits[beg:] += 4.0
+        hist = cs["hist"]
+        ts = [t for t in hist if t >= beg]
+        has_ts, seek_delta = len(ts) > 0, (2 * (ts[-1] - beg) if ts else 3000)
+        temp = cs.get("temp", 0.0)
+        p = eng.default_params(pkg.SAMPLING_GREEDY, **cs["kw"])
+        po = _oracle_params(orc, p)
+        rl, rlp, rp = orc.process_logits(po, logits, hist, temperature=temp, has_ts=has_ts, seek_delta=seek_delta)
+        gl, glp, gp, tok = eng.process_logits(p, logits, hist, temperature=temp, has_ts=has_ts, seek_delta=seek_delta)
+        assert (np.isneginf(gl) == np.isneginf(rl)).all(), ci      # suppression sets are identical
+        fin = ~np.isneginf(rl)
+        assert np.array_equal(gl[fin], rl[fin]), ci                 # surviving logits untouched (bit-exact)
+        assert np.abs(glp[fin] - rlp[fin]).max() < 2e-5, ci         # log-softmax: parallel vs serial fp32 sum
+        assert np.abs(gp - rp).max() < 1e-6, ci
+        # greedy pick = first maximum of the oracle's probabilities
+        assert tok[0]["id"] == int(np.argmax(rp)), ci
+        ts_p = rp[beg:]
+        assert abs(tok[0]["ptsum"] - ts_p.sum(dtype=np.float64)) < 1e-5
+        if tok[0]["id"] < beg and ts_p.max() > 0:
+            assert tok[0]["tid"] == beg + int(np.argmax(ts_p))
+
+
+def test_process_logits_regex_and_ties(pkg, engines, oracles):
+    eng, orc = engines("micro.en", pkg.PRECISION_FP32), oracles("micro.en")
+    nv = orc.n_vocab
+    logits = np.zeros(nv, np.float32)           # every unsuppressed token ties: the lowest id must win
+    p = eng.default_params(pkg.SAMPLING_GREEDY, suppress_blank=False, suppress_regex=r" ?[a-m].*")
+    po = orc.default_params(0, suppress_blank=0, suppress_regex=r" ?[a-m].*")
+    rl, rlp, rp = orc.process_logits(po, logits, [300, 400])
+    gl, glp, gp, tok = eng.process_logits(p, logits, [300, 400])
+    assert (np.isneginf(gl) == np.isneginf(rl)).all() and np.isneginf(gl).sum() > 10000
+    assert tok[0]["id"] == int(np.argmax(rp))
+
+
+def test_sampler_inverse_cdf(pkg, engines, oracles):
+    # the distribution std::discrete_distribution realises: normalised doubles, lower_bound
+    eng, orc = engines("micro.en", pkg.PRECISION_FP32), oracles("micro.en")
+    nv = orc.n_vocab
+    rs = np.random.RandomState(77)
+    logits = (rs.standard_normal(nv) * 4.0).astype(np.float32)
+    p = eng.default_params(pkg.SAMPLING_BEAM_SEARCH, suppress_blank=False)
+    po = orc.default_params(1, suppress_blank=0)
+    _, rlp, rp = orc.process_logits(po, logits, [300, 400])
+    pn = rp.astype(np.float64) / rp.astype(np.float64).sum()
+    cp = np.cumsum(pn)
+    cp[-1] = 1.0
+    u = np.array([1e-12, 0.1, 0.37, 0.5, 0.93, 0.999999, 0.25, 0.75])
+    _, _, _, toks = eng.process_logits(p, logits, [300, 400], n_draws=8, u=u)
+    for ui, t in zip(u, toks):
+        want = int(np.searchsorted(cp, ui, side="left"))
+        assert t["id"] == want, (ui, t["id"], want)
+        assert abs(t["p"] - rp[want]) < 1e-7 and abs(t["plog"] - rlp[want]) < 2e-5
+
+
+# ---------------------------------------------------------------------------------------------
+# whisper_full: tokens
+# ---------------------------------------------------------------------------------------------
+def _run_both(pkg, eng, orc, pcm, strategy, **kw):
+    p = eng.default_params(strategy, **kw)
+    okw = {}
+    for k, v in kw.items():
+        okw[k] = int(v) if isinstance(v, bool) else v
+    po = orc.default_params(strategy, **okw)
+    assert eng.full(p, pcm) == 0
+    assert orc.full(po, pcm) == 0
+    return eng.segments(), orc.segments()
+
+
+def _assert_same_segments(gs, rs):
+    assert len(gs) == len(rs)
+    for a, b in zip(gs, rs):
+        assert (a["t0"], a["t1"], a["text"]) == (b["t0"], b["t1"], b["text"])
+        assert [t["id"] for t in a["tokens"]] == [t["id"] for t in b["tokens"]]
+        assert [t["tid"] for t in a["tokens"]] == [t["tid"] for t in b["tokens"]]
+        for x, y in zip(a["tokens"], b["tokens"]):
+            assert abs(x["p"] - y["p"]) < 1e-4 and abs(x["plog"] - y["plog"]) < 2e-3
+
+
+@pytest.mark.parametrize("preset", ["micro.en", "micro"])
+def test_full_greedy_fp32_tokens_bit_exact(pkg, engines, oracles, preset):
+    # temperature_inc = 0: one greedy pass (temperature fallback is covered by the next test)
+    eng, orc = engines(preset, pkg.PRECISION_FP32), oracles(preset)
+    for seed, secs in ((0, 30.0), (1, 8.0)):
+        pcm = ggml_io.synth_pcm(seed, secs)
+        gs, rs = _run_both(pkg, eng, orc, pcm, pkg.SAMPLING_GREEDY, temperature_inc=0.0,
+                           duration_ms=int(secs * 1000), language="en")
+        assert sum(len(s["tokens"]) for s in rs) > 0
+        _assert_same_segments(gs, rs)
+
+
+def test_full_greedy_fallback_sampling_fp32(pkg, engines, oracles):
+    # default parameters: random weights fail the logprob threshold, so every temperature up to 1.0 is
+    # tried and best_of = 5 decoders sample from the distribution (host mt19937 -> device inverse CDF)
+    eng, orc = engines("micro.en", pkg.PRECISION_FP32), oracles("micro.en")
+    pcm = ggml_io.synth_pcm(3, 6.0)
+    gs, rs = _run_both(pkg, eng, orc, pcm, pkg.SAMPLING_GREEDY, duration_ms=6000)
+    _assert_same_segments(gs, rs)
+
+
+@pytest.mark.parametrize("preset", ["micro.en", "micro"])
+def test_full_beam_fp32_tokens(pkg, engines, oracles, preset):
+    eng, orc = engines(preset, pkg.PRECISION_FP32), oracles(preset)
+    pcm = ggml_io.synth_pcm(4, 10.0)
+    gs, rs = _run_both(pkg, eng, orc, pcm, pkg.SAMPLING_BEAM_SEARCH, temperature_inc=0.0, duration_ms=10000,
+                       suppress_blank=False)
+    _assert_same_segments(gs, rs)
+
+
+def test_full_forced_length_and_prompt(pkg, engines, oracles):
+    eng, orc = engines("micro.en", pkg.PRECISION_FP32), oracles("micro.en")
+    pcm = ggml_io.synth_pcm(6, 12.0)
+    eng.set_force_decode_steps(40)
+    try:
+        p = eng.default_params(pkg.SAMPLING_GREEDY, temperature_inc=0.0, duration_ms=12000, single_segment=True,
+                               initial_prompt=" hello world. this is a test", no_context=False)
+        po = orc.default_params(0, temperature_inc=0.0, duration_ms=12000, single_segment=1, force_decode_steps=40,
+                                initial_prompt=" hello world. this is a test", no_context=0)
+        assert eng.full(p, pcm) == 0 and orc.full(po, pcm) == 0
+        g, r = eng.token_ids(), orc.token_ids()
+        assert len(r) == 40 and g == r
+        # second call: prompt_past now carries the previous window's tokens (no_context = false)
+        assert eng.full(p, pcm) == 0 and orc.full(po, pcm) == 0
+        assert eng.token_ids() == orc.token_ids()
+    finally:
+        eng.set_force_decode_steps(0)
+
+
+def test_full_bf16_token_match_rate(pkg, engines, oracles):
+    # bf16 mode is not required to be bit-exact; report the match rate over a forced 48-token decode
+    eng, orc = engines("micro.en", pkg.PRECISION_BF16), oracles("micro.en")
+    pcm = ggml_io.synth_pcm(0, 30.0)
+    eng.set_force_decode_steps(48)
+    try:
+        p = eng.default_params(pkg.SAMPLING_GREEDY, temperature_inc=0.0, duration_ms=30000, single_segment=True)
+        po = orc.default_params(0, temperature_inc=0.0, duration_ms=30000, single_segment=1, force_decode_steps=48)
+        assert eng.full(p, pcm) == 0 and orc.full(po, pcm) == 0
+        g, r = eng.token_ids(), orc.token_ids()
+        assert len(g) == len(r) == 48
+        first_div = next((i for i, (a, b) in enumerate(zip(g, r)) if a != b), len(r))
+        print(f"bf16 vs fp32 oracle: first divergence at token {first_div} of {len(r)}")
+        assert first_div >= 1   # random weights: near-uniform logits, divergence is expected eventually
+    finally:
+        eng.set_force_decode_steps(0)
+
+
+def test_language_detect_and_short_input(pkg, engines, oracles):
+    eng, orc = engines("micro", pkg.PRECISION_FP32), oracles("micro")
+    pcm = ggml_io.synth_pcm(7, 4.0)
+    p = eng.default_params(pkg.SAMPLING_GREEDY, temperature_inc=0.0, language="auto", duration_ms=4000)
+    po = orc.default_params(0, temperature_inc=0.0, language="auto", duration_ms=4000)
+    assert eng.full(p, pcm) == 0 and orc.full(po, pcm) == 0
+    assert eng.L.whisper_full_lang_id(eng.ctx) == orc.L.ow_full_lang_id(orc.ctx)
+    lid, probs = eng.lang_auto_detect()
+    rid, rprobs = orc.lang_auto_detect()
+    assert lid == rid and np.abs(probs - rprobs).max() < 1e-4
+    _assert_same_segments(eng.segments(), orc.segments())
+    # detect_language = true: returns right after detection with no segments
+    p = eng.default_params(pkg.SAMPLING_GREEDY, detect_language=True, language="auto")
+    assert eng.full(p, pcm) == 0 and eng.segments() == []
+    # under one second: "input is too short" -> 0 and no segments (why LocalVocal pads)
+    p = eng.default_params(pkg.SAMPLING_GREEDY, duration_ms=900, language="en")
+    assert eng.full(p, pcm[:14400]) == 0 and eng.segments() == []
+    # English-only model: auto-detect is an error (-3), as in the oracle
+    eng2, orc2 = engines("micro.en", pkg.PRECISION_FP32), oracles("micro.en")
+    p = eng2.default_params(pkg.SAMPLING_GREEDY, language="auto")
+    po = orc2.default_params(0, language="auto")
+    assert eng2.full(p, pcm) == orc2.full(po, pcm) == -3
+
+
+# ---------------------------------------------------------------------------------------------
+# LocalVocal boundary: run_whisper_inference
+# ---------------------------------------------------------------------------------------------
+def _reference_post_filter(orc, segs, incoming_ms, psum_thresh, dur_thresh, partial):
+    """whisper-processing.cpp:246-323 restated over oracle segments (result, text, kept ids)."""
+    sentence_p, text, kept = np.float32(0), b"", []
+    for s in segs:
+        n = len(s["tokens"])
+        for j, t in enumerate(s["tokens"]):
+            piece = orc.token_to_str(t["id"])
+            keep = not (piece[:1] == b"[" and piece[-1:] == b"]") and t["id"] < 50256 and not (j == n - 2 and t["id"] == 13)
+            if 50365 < t["id"] <= 51865:
+                time = np.float32(np.float32(t["id"]) - np.float32(50365.0)) * np.float32(0.02)
+                if time / np.float32(np.float32(incoming_ms) / np.float32(1000.0)) > np.float32(dur_thresh):
+                    return 1, b"", []
+                keep = False
+            if keep:
+                sentence_p = np.float32(sentence_p + np.float32(t["p"]))
+                text += piece
+                kept.append(t["id"])
+    with np.errstate(all="ignore"):
+        sentence_p = sentence_p / np.float32(len(kept))
+    if sentence_p < psum_thresh:
+        return 1, b"", []
+    if text in (b"", b".", b" ", b"\n"):
+        return 1, b"", []
+    return (5 if partial else 2), text, kept
+
+
+@pytest.mark.parametrize("preset", ["micro.en", "micro"])
+def test_run_whisper_inference_matches_reference_contract(pkg, model_file, oracles, preset):
+    orc = oracles(preset)
+    f = pkg.Filter(precision=pkg.PRECISION_FP32)
+    try:
+        assert f.load_model(os.path.dirname(model_file(preset)) if False else model_file(preset)) == 0
+        f.params.temperature_inc = 0.0
+        f.L.lv_filter_set_thresholds(f.f, 0.0, 2.25)   # random weights: token p is tiny; accept everything
+        libc = ctypes.CDLL(None)
+        for seed, secs, vad in ((0, 3.0, 1), (1, 7.0, 3), (2, 0.6, 1)):
+            pcm = np.r_[np.zeros(160, np.float32), ggml_io.synth_pcm(seed, secs), np.zeros(160, np.float32)]
+            libc.srand(1234)
+            out = f.run_whisper_inference(pcm, 1000, 1000 + int(secs * 1000), vad)
+            # oracle side: same padding rule (rand() replayed), same params as the filter's defaults
+            libc.srand(1234)
+            if len(pcm) < 16000:
+                n_new = int(np.float32(1.01) * np.float32(16000))
+                libc.rand.restype = ctypes.c_int
+                noise = np.array([np.float32(0.01) * (np.float32(libc.rand()) / np.float32(2147483647) * np.float32(2.0)
+                                                      - np.float32(1.0)) for _ in range(n_new)], np.float32)
+                off = (n_new - len(pcm)) // 2
+                noise[off:off + len(pcm)] = pcm
+                fed = noise
+            else:
+                fed = pcm
+            po = orc.default_params(1, temperature_inc=0.0, suppress_blank=0, language="en",
+                                    duration_ms=int(len(fed) * 1000 // 16000))
+            assert orc.full(po, fed) == 0
+            res, text, kept = _reference_post_filter(orc, orc.segments(), len(pcm) * 1000 // 16000, 0.0, 2.25, vad == 3)
+            assert out["result"] == res, (seed, out, res)
+            assert out["text"] == text and [t["id"] for t in out["tokens"]] == kept
+            assert (out["start"], out["end"], out["language"]) == (1000, 1000 + int(secs * 1000), "en")
+        # guards (whisper-processing.cpp:133-148)
+        assert f.run_whisper_inference(None, 0, 1000)["result"] == 0
+        assert f.run_whisper_inference(np.zeros(16000, np.float32), 100, 120)["result"] == 0
+        # default acceptance threshold 0.4 rejects random-weight output as SILENCE
+        f.L.lv_filter_set_thresholds(f.f, 0.4, 2.25)
+        assert f.run_whisper_inference(ggml_io.synth_pcm(0, 3.0), 0, 3000)["result"] == 1
+    finally:
+        f.close()
+
+
+def test_model_dir_and_bad_files(pkg, model_file, tmp_path):
+    import shutil
+    d = tmp_path / "ggml-model-dir"
+    d.mkdir()
+    (d / "readme.txt").write_text("x")
+    f = pkg.Filter(precision=pkg.PRECISION_FP32)
+    try:
+        assert f.load_model(str(d)) != 0                      # directory without a .bin
+        shutil.copy(model_file("micro.en"), d / "weights.bin")
+        assert f.load_model(str(d)) == 0                      # directory -> first *.bin
+        assert f.load_model(str(d)) == -2                     # already loaded
+    finally:
+        f.close()
+    bad = tmp_path / "bad.bin"
+    bad.write_bytes(b"\x00" * 4096)
+    with pytest.raises(RuntimeError):
+        pkg.Engine(str(bad))
+    trunc = tmp_path / "trunc.bin"
+    trunc.write_bytes(open(model_file("micro.en"), "rb").read(1 << 20))
+    with pytest.raises(RuntimeError):
+        pkg.Engine(str(trunc))
+    # buffer variant copies what it needs (caller frees right away, whisper-processing.cpp:104-110)
+    L = pkg.lib()
+    data = bytearray(open(model_file("micro.en"), "rb").read())
+    buf = (ctypes.c_char * len(data)).from_buffer(data)
+    ctx = L.mw_init_from_buffer(ctypes.addressof(buf), len(data), 0, pkg.PRECISION_FP32)
+    assert ctx
+    for i in range(0, len(data), 4096):
+        data[i] = 0xFF
+    eng = pkg.Engine("", ctx=ctx)
+    assert eng.mel(ggml_io.synth_pcm(0, 1.5)).shape[0] == 80
+    L.whisper_free(ctx)
