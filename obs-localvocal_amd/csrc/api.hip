@@ -551,7 +551,8 @@ int mw_bench_mel(struct whisper_context *ctx, int n_samples, int iters, float *m
         *ms_per_call = time_launches(c, iters, [&]() {
             launch_mel_frames(c.d_pcm, 0, n_samples, 1, c.model.d_mel_tab, c.d_mel_raw, (long)c.mel_cap_frames * n_mel,
                               n_active, n_mel, c.d_gmax, c.st);
-            launch_mel_normalize(c.d_mel_raw, 0, c.d_mel, 0, c.n_len, n_active, n_mel, 1, c.d_gmax, c.st);
+            launch_mel_normalize(c.d_mel_raw, (long)c.mel_cap_frames * n_mel, c.d_mel, (long)c.mel_cap_frames * n_mel, c.n_len,
+                                 n_active, n_mel, 1, c.d_gmax, c.st);
         });
         return 0;
     });

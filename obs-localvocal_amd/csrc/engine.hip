@@ -141,7 +141,8 @@ void pcm_to_mel(Context &c, const float *pcm, int n_samples, bool pcm_on_device)
     }
     launch_mel_frames(c.d_pcm, 0, n_samples, 1, c.model.d_mel_tab, c.d_mel_raw, (long)c.mel_cap_frames * n_mel, n_active,
                       n_mel, c.d_gmax, c.st);
-    launch_mel_normalize(c.d_mel_raw, 0, c.d_mel, 0, n_len, n_active, n_mel, 1, c.d_gmax, c.st);
+    launch_mel_normalize(c.d_mel_raw, (long)c.mel_cap_frames * n_mel, c.d_mel, (long)c.mel_cap_frames * n_mel, n_len,
+                         n_active, n_mel, 1, c.d_gmax, c.st);
     c.n_len = n_len;
     c.n_len_org = 1 + (n_samples + MEL_N_FFT / 2 - MEL_N_FFT) / MEL_HOP;
     c.tm.mel_ms += now_ms() - t0;
