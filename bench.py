@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""bench.py — audio-seconds transcribed per wall-second, Whisper large-v3 on MI355X.
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): Whisper large-v3 dims
+(d=1280, 32+32 layers, 128 mel bins, vocab 51866), bf16, beam search (beam_size 5) with timestamps,
+ONE stream per GPU, one 30 s 16 kHz window per step: log-mel -> encoder -> cross-K/V -> prompt prefill
+-> 128 beam-5 decode steps with the logits rules + samplers on the device -> segments.
+Weights are seeded synthetic tensors in the real GGML container (no checkpoints offline), parsed and
+uploaded by the engine's own loader; PCM is synthetic and already resident in HBM when the timed region
+starts.  The decode length is forced to 128 sampled tokens per window (mw_set_force_decode_steps:
+random weights would otherwise stop after a handful of tokens), and temperature fallback is off
+(temperature_inc = 0) so every step does the same work.
+
+`--gpus N` (launched by torch.distributed.run, one rank per GPU): stream i -> GPU i, no data-path
+collective; value = all ranks' audio seconds / max-over-ranks time; scaling "weak".
+
+One JSON line on rank 0 (see the contract in the task statement) with two extra objects:
+  roofline     the dominant kernel (a weight-streaming projection class of the decode step): algorithmic
+               bytes per launch / average launch duration measured live with HIP events on the engine's
+               stream during the timed region, against 8 TB/s HBM
+  cpu_baseline the CPU oracle (a port, NOT whisper.cpp) timed on the box's host cores on a bounded sample
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import importlib.util
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def load_package():
+    spec = importlib.util.spec_from_file_location("obs_localvocal_amd", os.path.join(ROOT, "obs-localvocal_amd", "__init__.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["obs_localvocal_amd"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+GEMV_CLASSES = {"qkv": 0, "attn_out": 1, "cross_q": 2, "fc1": 3, "fc2": 4, "logits": 5}
+
+
+def gemv_bytes(cls: str, d: int, n_vocab: int, rows: int, wbytes: int) -> int:
+    """Algorithmic HBM bytes of ONE launch of a projection class."""
+    N, K = {"qkv": (3 * d, d), "attn_out": (d, d), "cross_q": (d, d), "fc1": (4 * d, d), "fc2": (d, 4 * d),
+            "logits": (n_vocab, d)}[cls]
+    resid = cls in ("attn_out", "fc2")
+    return N * K * wbytes + N * 4 + rows * K * 4 + rows * N * 4 * (2 if resid else 1)
+
+
+def cpu_baseline(model_path: str, pcm: np.ndarray, beam: int, decode_steps: int, sample_steps: int, threads: int):
+    """Time the CPU oracle (port) on a bounded sample: mel + full encoder + `sample_steps` beam decode
+    steps of the same window; the per-step time extrapolates to `decode_steps`."""
+    from oracle import pyoracle
+    pyoracle.lib().ow_set_threads(threads)
+    t0 = time.time()
+    orc = pyoracle.Oracle(model_path)
+    t_load = time.time() - t0
+    t0 = time.time()
+    orc.mel(pcm)
+    t_mel = time.time() - t0
+    t0 = time.time()
+    orc.encode(0)
+    t_enc = time.time() - t0
+    p = orc.default_params(1, temperature_inc=0.0, duration_ms=30000, language="en", force_decode_steps=sample_steps,
+                           beam_size=beam)
+    t0 = time.time()
+    rc = orc.full(p, pcm)
+    t_full = time.time() - t0
+    assert rc == 0, rc
+    per_step = max(t_full - t_mel - t_enc, 1e-9) / sample_steps
+    est = t_mel + t_enc + per_step * decode_steps
+    orc.close()
+    return dict(value=round(30.0 / est, 4), unit="audio-sec/sec", cores=threads, kind="port",
+                sample=("CPU oracle (fp32 restatement, OpenMP; not whisper.cpp): one 30 s window, mel %.2fs + full "
+                        "32-layer encoder %.1fs measured, %d of %d beam-%d decode steps measured (%.3fs/step incl. prefill) "
+                        "and extrapolated to %d; model load %.0fs excluded" %
+                        (t_mel, t_enc, sample_steps, decode_steps, beam, per_step, decode_steps, t_load)))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--model", default="large-v3")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--beam", type=int, default=5)
+    ap.add_argument("--decode-steps", type=int, default=128)
+    ap.add_argument("--roofline-class", default="fc2", choices=sorted(GEMV_CLASSES))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-steps", type=int, default=12)
+    ap.add_argument("--model-dir", default=os.environ.get("MI355_WHISPER_BENCH_DIR", "/tmp/mi355_whisper_bench"))
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    n_gpus = max(world, 1)
+    if a.gpus != n_gpus and rank == 0:
+        print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; reporting n_gpus={n_gpus}", file=sys.stderr)
+
+    pkg = load_package()
+    from tools import ggml_io, synth_large
+
+    # ---- model file: written once per node by local rank 0 ----
+    os.makedirs(a.model_dir, exist_ok=True)
+    model_path = os.path.join(a.model_dir, f"ggml-{a.model}-synth-s1234.bin")
+    if local_rank == 0 and not os.path.exists(model_path):
+        t0 = time.time()
+        synth_large.write_large(model_path, a.model, seed=1234, quiet_special=True)
+        print(f"[bench] wrote synthetic {a.model} weights in {time.time() - t0:.1f}s -> {model_path}", file=sys.stderr)
+    if dist is not None:
+        dist.barrier()
+    else:
+        while not os.path.exists(model_path):
+            time.sleep(0.5)
+
+    torch.cuda.set_device(local_rank)
+    t0 = time.time()
+    eng = pkg.Engine(model_path, precision=pkg.PRECISION_BF16 if a.precision == "bf16" else pkg.PRECISION_FP32,
+                     device=local_rank)
+    t_load = time.time() - t0
+    eng.set_force_decode_steps(a.decode_steps)
+    params = eng.default_params(pkg.SAMPLING_BEAM_SEARCH, temperature_inc=0.0, duration_ms=30000, language="en",
+                                beam_size=a.beam)
+    pcm_host = ggml_io.synth_pcm(100 + rank, 30.0)
+    pcm = torch.from_numpy(pcm_host).cuda(local_rank)
+    torch.cuda.synchronize()
+
+    def step():
+        rc = eng.full_device(params, pcm.data_ptr(), pcm.numel())
+        if rc != 0:
+            raise RuntimeError(f"whisper_full failed: {rc} {pkg.last_error()}")
+
+    for _ in range(a.warmup):
+        step()
+    n_tok = len(eng.token_ids())
+    eng.reset_timings()
+
+    def sync_all():
+        torch.cuda.synchronize()
+        eng.L.mw_synchronize(eng.ctx)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    cls = a.roofline_class
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    tm = eng.timings()
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # roofline leg: the same step, launch by launch (graphs off while a projection class is bracketed by
+    # HIP events on the engine's stream), right after the timed region, same process, same weights
+    n_launch, tot_ms = C.c_int(0), C.c_float(0)
+    if rank == 0:
+        eng.L.mw_profile_begin(eng.ctx, GEMV_CLASSES[cls], 200000)
+        for _ in range(max(1, min(a.steps, 2))):
+            step()
+        eng.L.mw_profile_end(eng.ctx, C.byref(n_launch), C.byref(tot_ms))
+    if rank == 0:
+        audio_s = 30.0 * a.steps * n_gpus
+        value = audio_s / elapsed
+        ms_per_step = 1000.0 * elapsed / a.steps
+        wbytes = 2 if a.precision == "bf16" else 4
+        rows = a.beam
+        b_launch = gemv_bytes(cls, eng.n_text_state, eng.n_vocab, rows, wbytes)
+        avg_ms = tot_ms.value / max(n_launch.value, 1)
+        achieved = b_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        out = {
+            "metric": "audio-sec transcribed/sec", "value": round(value, 2), "unit": "audio-sec/sec",
+            "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": a.precision, "data": "synthetic",
+            "config": {"workload": f"whisper {a.model} {a.precision}, beam={a.beam} with timestamps, 1 stream/GPU, "
+                                   f"30 s window/step, {a.decode_steps} forced decode steps, synthetic GGML weights (seed 1234)",
+                       "streams_per_gpu": 1, "window_s": 30, "beam_size": a.beam, "decode_steps": a.decode_steps,
+                       "tokens_per_window": n_tok, "parallelism": f"streams x{n_gpus} (no collectives)"},
+            "rtf_per_stream": round(ms_per_step / 30000.0, 6),
+            "breakdown_ms_per_step": {"mel": round(tm.mel_ms / a.steps, 3), "encoder+crossKV(host-side launch)": round(tm.encode_ms / a.steps, 3),
+                                      "decode": round(tm.decode_ms / a.steps, 3), "rules+sample(sync)": round(tm.sample_ms / a.steps, 3),
+                                      "decode_calls": tm.n_decode // max(a.steps, 1)},
+            "model_load_s": round(t_load, 2),
+            "roofline": {"bound": "hbm", "kernel": f"gemv_kernel<{a.precision},NB={rows},class={cls}>",
+                         "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(achieved / 8000.0, 4), "traffic": None,
+                         "bytes_per_launch": b_launch, "avg_launch_us": round(avg_ms * 1000.0, 3),
+                         "launches_timed": n_launch.value},
+        }
+        if not a.no_cpu_baseline and n_gpus == 1:
+            threads = min(16, os.cpu_count() or 1)
+            try:
+                out["cpu_baseline"] = cpu_baseline(model_path, pcm_host, a.beam, a.decode_steps, a.cpu_sample_steps, threads)
+            except Exception as e:  # the baseline is a reported side figure; never fail the bench on it
+                out["cpu_baseline"] = {"value": None, "unit": "audio-sec/sec", "cores": threads, "kind": "port",
+                                       "sample": f"failed: {e}"}
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

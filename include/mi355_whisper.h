@@ -37,6 +37,9 @@ int mw_pcm_to_mel(struct whisper_context *ctx, const float *samples, int n_sampl
 /* same, PCM already resident in HBM (the timed region of bench.py starts here) */
 int mw_pcm_to_mel_device(struct whisper_context *ctx, const float *samples_device, int n_samples);
 int mw_mel_n_len(struct whisper_context *ctx);
+/* whisper_full (whisper-processing.cpp:218-219) with the PCM already resident in HBM on the context's device */
+int mw_full_device(struct whisper_context *ctx, struct whisper_full_params params, const float *samples_device,
+                   int n_samples);
 /* out[n_mel][n_len] (whisper.cpp layout) */
 int mw_get_mel(struct whisper_context *ctx, float *out);
 /* encoder + cross-K/V for the 30 s window starting at mel frame `seek` */
@@ -80,6 +83,13 @@ int mw_set_force_decode_steps(struct whisper_context *ctx, int n);
 int mw_bench_decode_step(struct whisper_context *ctx, int rows, int n_past, int iters, float *ms_per_step);
 int mw_bench_mel(struct whisper_context *ctx, int n_samples, int iters, float *ms_per_call);
 int mw_bench_encode(struct whisper_context *ctx, int iters, float *ms_per_call);
+
+/* Live timing of ONE projection class of the decode step (the weight-streaming kernels of dec.hip):
+   between begin and end every launch of that class on the context's stream is bracketed by HIP events;
+   end returns the launch count and the summed elapsed time.  Classes: */
+enum mw_gemv_class { MW_GEMV_QKV = 0, MW_GEMV_ATTN_OUT = 1, MW_GEMV_CROSS_Q = 2, MW_GEMV_FC1 = 3, MW_GEMV_FC2 = 4, MW_GEMV_LOGITS = 5 };
+int mw_profile_begin(struct whisper_context *ctx, int gemv_class, int max_launches);
+int mw_profile_end(struct whisper_context *ctx, int *n_launches, float *total_ms);
 
 const char *mw_last_error(void);
 

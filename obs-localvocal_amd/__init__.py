@@ -100,6 +100,7 @@ EXPORTED_SYMBOLS = [
     "whisper_n_len", "whisper_token_eot", "whisper_token_sot", "whisper_token_solm", "whisper_token_prev",
     "whisper_token_nosp", "whisper_token_not", "whisper_token_beg", "whisper_token_lang", "whisper_token_translate",
     "whisper_token_transcribe", "whisper_tokenize",
+    "mw_full_device", "mw_profile_begin", "mw_profile_end",
     "mw_init_from_file", "mw_init_from_buffer", "mw_hparams", "mw_pcm_to_mel", "mw_pcm_to_mel_device", "mw_mel_n_len",
     "mw_get_mel", "mw_encode", "mw_get_encoder_out", "mw_get_cross_kv", "mw_decode", "mw_get_logits", "mw_kv_clear",
     "mw_process_logits", "mw_get_timings", "mw_reset_timings", "mw_stream", "mw_synchronize",
@@ -172,6 +173,7 @@ def lib():
     L.mw_pcm_to_mel.argtypes = [P, FP, C.c_int]
     L.mw_pcm_to_mel_device.argtypes = [P, P, C.c_int]
     L.mw_mel_n_len.argtypes = [P]
+    L.mw_full_device.argtypes = [P, FullParams, P, C.c_int]
     L.mw_get_mel.argtypes = [P, FP]
     L.mw_encode.argtypes = [P, C.c_int, C.c_int]
     L.mw_get_encoder_out.argtypes = [P, FP]
@@ -191,6 +193,8 @@ def lib():
     L.mw_bench_mel.argtypes = [P, C.c_int, C.c_int, FP]
     L.mw_bench_encode.argtypes = [P, C.c_int, FP]
     L.mw_last_error.restype = C.c_char_p
+    L.mw_profile_begin.argtypes = [P, C.c_int, C.c_int]
+    L.mw_profile_end.argtypes = [P, C.POINTER(C.c_int), FP]
     L.lv_filter_create.restype = P
     L.lv_filter_destroy.argtypes = [P]
     L.lv_filter_params.restype = C.POINTER(FullParams)
@@ -316,6 +320,10 @@ class Engine:
     def full(self, params: FullParams, pcm: np.ndarray) -> int:
         pcm = np.ascontiguousarray(pcm, dtype=np.float32)
         return self.L.whisper_full(self.ctx, params, _fp(pcm), len(pcm))
+
+    def full_device(self, params: FullParams, pcm_device_ptr: int, n_samples: int) -> int:
+        """whisper_full with the PCM already in HBM (pcm_device_ptr: e.g. torch tensor .data_ptr())."""
+        return self.L.mw_full_device(self.ctx, params, C.c_void_p(pcm_device_ptr), n_samples)
 
     def segments(self):
         out = []

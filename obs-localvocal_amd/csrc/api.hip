@@ -228,6 +228,14 @@ int whisper_full(struct whisper_context *ctx, struct whisper_full_params params,
     });
 }
 
+int mw_full_device(struct whisper_context *ctx, struct whisper_full_params params, const float *samples_device, int n_samples) {
+    if (!ctx || !ctx->c || !samples_device || n_samples <= 0) return -1;
+    return guarded("mw_full_device", [&]() {
+        DeviceGuard g(*ctx->c);
+        return full(*ctx->c, params, samples_device, n_samples, true);
+    });
+}
+
 int whisper_full_n_segments(struct whisper_context *ctx) { return ctx && ctx->c ? (int)ctx->c->result_all.size() : 0; }
 int whisper_full_n_tokens(struct whisper_context *ctx, int i) {
     if (!ctx || !ctx->c || i < 0 || i >= (int)ctx->c->result_all.size()) return 0;
@@ -525,6 +533,40 @@ int mw_set_force_decode_steps(struct whisper_context *ctx, int n) {
     return 0;
 }
 
+int mw_profile_begin(struct whisper_context *ctx, int gemv_class, int max_launches) {
+    if (!ctx || !ctx->c || gemv_class < 0 || gemv_class >= GEMV_N_TAGS || max_launches <= 0 || max_launches > (1 << 20)) return -1;
+    return guarded("mw_profile_begin", [&]() {
+        Context &c = *ctx->c;
+        DeviceGuard g(c);
+        while ((int)c.prof_ev.size() < 2 * max_launches) {
+            hipEvent_t e;
+            MW_HIP(hipEventCreate(&e));
+            c.prof_ev.push_back(e);
+        }
+        c.prof_n = 0;
+        c.prof_tag = gemv_class;
+        return 0;
+    });
+}
+int mw_profile_end(struct whisper_context *ctx, int *n_launches, float *total_ms) {
+    if (!ctx || !ctx->c || !n_launches || !total_ms) return -1;
+    return guarded("mw_profile_end", [&]() {
+        Context &c = *ctx->c;
+        DeviceGuard g(c);
+        MW_HIP(hipStreamSynchronize(c.st));
+        float total = 0.0f;
+        for (int i = 0; i + 1 < c.prof_n; i += 2) {
+            float ms = 0.0f;
+            MW_HIP(hipEventElapsedTime(&ms, c.prof_ev[i], c.prof_ev[i + 1]));
+            total += ms;
+        }
+        *n_launches = c.prof_n / 2;
+        *total_ms = total;
+        c.prof_tag = -1;
+        c.prof_n = 0;
+        return 0;
+    });
+}
 int mw_bench_decode_step(struct whisper_context *ctx, int rows, int n_past, int iters, float *ms_per_step) {
     if (!ctx || !ctx->c || rows <= 0 || rows > MAX_DECODERS || iters <= 0 || !ms_per_step) return -1;
     return guarded("mw_bench_decode_step", [&]() {

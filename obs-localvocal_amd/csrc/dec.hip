@@ -20,9 +20,20 @@ namespace mw {
 
 namespace {
 
+// wave64 sum through DPP (VALU cross-lane moves, no LDS round trips): quad xor-1/xor-2, half-row and
+// row mirrors give every lane its 16-lane row total; row_bcast15 / row_bcast31 chain the four rows so
+// lane 63 holds the wave total, which v_readlane broadcasts as a scalar.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v += dpp_f<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+    v += dpp_f<0x141, 0xf>(v);  // row_half_mirror
+    v += dpp_f<0x140, 0xf>(v);  // row_mirror
+    v += dpp_f<0x142, 0xa>(v);  // row_bcast15 into rows 1 and 3
+    v += dpp_f<0x143, 0xc>(v);  // row_bcast31 into rows 2 and 3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
@@ -88,114 +99,220 @@ template <typename WT> __device__ __forceinline__ int xs_index(int k, int KC) {
     else return k;
 }
 
-template <typename WT, typename KVT, int NB, int R>
-__global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a, int row0, int KC) {
+// TAG (GEMV_* in kernels.hpp) names the projection class: each class is its own kernel symbol, so
+// rocprofv3 statistics and the live HIP-event measurement in bench.py address the same launches.  It
+// also fixes the K-chunking at compile time: classes with K = d (<= 1280) hold the whole activation row
+// set in LDS (one chunk, LayerNorm fusable); GEMV_FC2 (K = 4d) walks chunks of 1024.
+//
+// Memory-level parallelism is the whole game here (a wave that waits for each 16-byte load before
+// issuing the next one runs at ~4 % of HBM): EVERY weight load of the wave's R rows is issued before
+// anything else — they do not depend on the activations — and lands in registers while the block
+// stages / normalises the activation rows.
+template <int TAG, int EPC> struct GemvShape {
+    static constexpr int KC_FIXED = TAG == GEMV_FC2 ? 1024 : 0;                // 0: chunk = K (runtime)
+    static constexpr int NCH = TAG == GEMV_FC2 ? 5 : 1;                        // max chunks
+    static constexpr int NLC = TAG == GEMV_FC2 ? 1024 / (64 * EPC) : (1280 + 64 * EPC - 1) / (64 * EPC);  // loads per lane per chunk
+};
+
+template <typename WT, typename KVT, int NB, int R, int TAG>
+__global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a, int row0) {
     constexpr int EPC = Epc<WT>::v;
-    extern __shared__ __attribute__((aligned(16))) float xs[];  // [NB][KC]
+    using S = GemvShape<TAG, EPC>;
+    constexpr int NCH = S::NCH, NLC = S::NLC;
+    constexpr int G = NCH == 1 ? 2 : 1;  // float4 groups of one activation row chunk per thread (KC/4 <= 256 G)
+    extern __shared__ __attribute__((aligned(16))) float xs[];  // [NCH > 1 ? 2 : 1][NB][KC]
+    __shared__ float red[4][NB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = a.K, N = a.N;
+    const int KC = S::KC_FIXED ? S::KC_FIXED : K;
+    const int nch = S::KC_FIXED ? (K + KC - 1) / KC : 1;
     const int nb_valid = min(NB, a.n - row0);
     const int n_base = (blockIdx.x * 4 + wave) * R;
+    const int kc4 = KC >> 2;
 
+    // (weight loads are issued below, right after the activation loads: vmcnt retires in order, so the
+    //  L2-resident activations must be OLDER than the HBM weight stream for LayerNorm to overlap it)
+    // 2. epilogue operands: lane r*NB+b owns output (row b, feature n_base+r); fetch its bias / residual now
+    const int my_r = lane / NB, my_b = lane - my_r * NB;
+    const bool my_out = lane < R * NB && my_b < nb_valid && n_base + my_r < N;
+    float my_bias = 0.0f, my_res = 0.0f;
+    if (my_out) {
+        if (a.bias) my_bias = a.bias[n_base + my_r];
+        if (a.R && !a.qkv) my_res = a.R[(long)(row0 + my_b) * a.ldo + n_base + my_r];
+    }
+    // 3. activation rows (first chunk) and LayerNorm parameters
+    int xrow[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int row = row0 + min(b, nb_valid - 1);  // rows beyond the valid count replicate the last; never stored
+        xrow[b] = a.d_rows ? a.d_rows[row] : row;
+    }
+    float4 xr[NB][G];
+    auto load_x = [&](int c) {
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            const int g = tid + 256 * j, k = c * KC + 4 * g;
+            const bool ok = g < kc4 && k < K;
+            const int kk = ok ? k : 0;  // clamped address + select instead of an exec-masked branch per load
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const float4 t = *reinterpret_cast<const float4 *>(a.x + (long)xrow[b] * a.ldx + kk);
+                xr[b][j] = ok ? t : make_float4(0, 0, 0, 0);
+            }
+        }
+    };
+    auto store_x = [&](float *dst) {
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            const int g = tid + 256 * j;
+            if (g < kc4) {
+                int slot;
+                if constexpr (EPC == 8) slot = (g & 1) * (KC >> 1) + ((g >> 1) << 2);
+                else slot = 4 * g;
+#pragma unroll
+                for (int b = 0; b < NB; ++b) *reinterpret_cast<float4 *>(dst + b * KC + slot) = xr[b][j];
+            }
+        }
+    };
+    load_x(0);
+    float4 lw[G], lb[G];
+    const bool do_ln = NCH == 1 && a.ln_w != nullptr;
+    if (do_ln) {
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            const int g = min(tid + 256 * j, kc4 - 1);
+            lw[j] = *reinterpret_cast<const float4 *>(a.ln_w + 4 * g);
+            lb[j] = *reinterpret_cast<const float4 *>(a.ln_b + 4 * g);
+        }
+    }
+    // every weight load of this wave, up front: independent of the activations, in flight during LayerNorm
+    uint4 wv[NCH][R][NLC];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const WT *wrow = (const WT *)a.W + (long)min(n_base + r, N - 1) * K;
+#pragma unroll
+            for (int i = 0; i < NLC; ++i) {
+                const int kin = lane * EPC + i * 64 * EPC, k = c * KC + kin;
+                const bool ok = c < nch && kin < KC && k < K;
+                const uint4 t = ld_stream16(wrow + (ok ? k : 0));
+                wv[c][r][i] = ok ? t : make_uint4(0, 0, 0, 0);
+            }
+        }
+    if (do_ln) {
+        // fused LayerNorm on the register copy: mean, then centred variance (two passes, like ggml_norm)
+        float part[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            float s = 0.0f;
+#pragma unroll
+            for (int j = 0; j < G; ++j) s += (xr[b][j].x + xr[b][j].y) + (xr[b][j].z + xr[b][j].w);
+            part[b] = wave_sum(s);
+        }
+        if (lane == 0)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) red[wave][b] = part[b];
+        __syncthreads();
+        float mean[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) mean[b] = ((red[0][b] + red[1][b]) + (red[2][b] + red[3][b])) / (float)K;
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            float s = 0.0f;
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                if (tid + 256 * j < kc4) {
+                    xr[b][j].x -= mean[b]; xr[b][j].y -= mean[b]; xr[b][j].z -= mean[b]; xr[b][j].w -= mean[b];
+                    s += (xr[b][j].x * xr[b][j].x + xr[b][j].y * xr[b][j].y) + (xr[b][j].z * xr[b][j].z + xr[b][j].w * xr[b][j].w);
+                }
+            }
+            part[b] = wave_sum(s);
+        }
+        if (lane == 0)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) red[wave][b] = part[b];
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const float rstd = 1.0f / sqrtf(((red[0][b] + red[1][b]) + (red[2][b] + red[3][b])) / (float)K + 1e-5f);
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                xr[b][j].x = xr[b][j].x * rstd * lw[j].x + lb[j].x;
+                xr[b][j].y = xr[b][j].y * rstd * lw[j].y + lb[j].y;
+                xr[b][j].z = xr[b][j].z * rstd * lw[j].z + lb[j].z;
+                xr[b][j].w = xr[b][j].w * rstd * lw[j].w + lb[j].w;
+            }
+        }
+    }
     float acc[R][NB];
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int b = 0; b < NB; ++b) acc[r][b] = 0.0f;
 
-    const WT *wrow[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) wrow[r] = (const WT *)a.W + (long)min(n_base + r, N - 1) * K;
-
-    for (int kc = 0; kc < K; kc += KC) {
-        if (kc > 0) __syncthreads();
-        // stage the activation chunk (rows beyond the valid count replicate the last row; never stored)
-        for (int idx = tid; idx < NB * KC; idx += 256) {
-            const int b = idx / KC, k = idx - b * KC;
-            int row = row0 + min(b, nb_valid - 1);
-            if (a.d_rows) row = a.d_rows[row];
-            xs[b * KC + xs_index<WT>(k, KC)] = a.x[(long)row * a.ldx + kc + k];
-        }
-        __syncthreads();
-        if (a.ln_w) {  // fused LayerNorm (requires K == KC): wave w normalises rows w, w+4
-            for (int b = wave; b < NB; b += 4) {
-                float *xr = xs + b * KC;
-                float s = 0.0f;
-                for (int k = lane; k < KC; k += 64) s += xr[k];
-                const float mean = wave_sum(s) / (float)KC;
-                float s2 = 0.0f;
-                for (int k = lane; k < KC; k += 64) {
-                    const float v = xr[k] - mean;
-                    s2 += v * v;
-                }
-                const float rstd = 1.0f / sqrtf(wave_sum(s2) / (float)KC + 1e-5f);
-                for (int k = lane; k < KC; k += 64) {
-                    const int i = xs_index<WT>(k, KC);
-                    xr[i] = (xr[i] - mean) * rstd * a.ln_w[k] + a.ln_b[k];
-                }
-            }
-            __syncthreads();
-        }
-        if (n_base < N) {
-            for (int k = lane * EPC; k < KC; k += 64 * EPC) {
-                uint4 wv[R];
+    for (int c = 0; c < NCH; ++c) {
+        if (c < nch) {
+            float *xc = xs + (NCH > 1 ? (c & 1) * NB * KC : 0);
+            store_x(xc);
+            if (NCH > 1 && c + 1 < nch) load_x(c + 1);  // next chunk's loads fly during this chunk's FMAs
+            __syncthreads();  // double-buffered: chunk c-1's readers are past the previous barrier
 #pragma unroll
-                for (int r = 0; r < R; ++r)
-                    wv[r] = ld_stream16(wrow[r] + kc + k);
-                float wf[R][EPC];
+            for (int i = 0; i < NLC; ++i) {
+                const int kin = lane * EPC + i * 64 * EPC;
+                if (kin < KC) {
+                    float wf[R][EPC];
 #pragma unroll
-                for (int r = 0; r < R; ++r) unpack(wv[r], wf[r], WT{});
+                    for (int r = 0; r < R; ++r) unpack(wv[c][r][i], wf[r], WT{});
 #pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    float xv[EPC];
-                    if constexpr (EPC == 8) {
-                        const float4 lo = *reinterpret_cast<const float4 *>(xs + b * KC + ((k >> 3) << 2));
-                        const float4 hi = *reinterpret_cast<const float4 *>(xs + b * KC + (KC >> 1) + ((k >> 3) << 2));
-                        xv[0] = lo.x; xv[1] = lo.y; xv[2] = lo.z; xv[3] = lo.w;
-                        xv[4] = hi.x; xv[5] = hi.y; xv[6] = hi.z; xv[7] = hi.w;
-                    } else {
-                        const float4 lo = *reinterpret_cast<const float4 *>(xs + b * KC + k);
-                        xv[0] = lo.x; xv[1] = lo.y; xv[2] = lo.z; xv[3] = lo.w;
+                    for (int b = 0; b < NB; ++b) {
+                        float xv[EPC];
+                        if constexpr (EPC == 8) {
+                            const float4 lo = *reinterpret_cast<const float4 *>(xc + b * KC + ((kin >> 3) << 2));
+                            const float4 hi = *reinterpret_cast<const float4 *>(xc + b * KC + (KC >> 1) + ((kin >> 3) << 2));
+                            xv[0] = lo.x; xv[1] = lo.y; xv[2] = lo.z; xv[3] = lo.w;
+                            xv[4] = hi.x; xv[5] = hi.y; xv[6] = hi.z; xv[7] = hi.w;
+                        } else {
+                            const float4 lo = *reinterpret_cast<const float4 *>(xc + b * KC + kin);
+                            xv[0] = lo.x; xv[1] = lo.y; xv[2] = lo.z; xv[3] = lo.w;
+                        }
+#pragma unroll
+                        for (int r = 0; r < R; ++r)
+#pragma unroll
+                            for (int e = 0; e < EPC; ++e) acc[r][b] = fmaf(wf[r][e], xv[e], acc[r][b]);
                     }
-#pragma unroll
-                    for (int r = 0; r < R; ++r)
-#pragma unroll
-                        for (int e = 0; e < EPC; ++e) acc[r][b] = fmaf(wf[r][e], xv[e], acc[r][b]);
                 }
             }
         }
     }
+    // reduce over the wave; every lane ends with every sum, lane r*NB+b keeps its own
+    float mine = 0.0f;
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
-        for (int b = 0; b < NB; ++b) acc[r][b] = wave_sum(acc[r][b]);
-    if (lane == 0) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int n = n_base + r;
-            if (n >= N) continue;
-            const float bias = a.bias ? a.bias[n] : 0.0f;
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                if (b >= nb_valid) continue;
-                const int row = row0 + b;
-                float v = acc[r][b] + bias;
-                if (a.qkv) {
-                    const int d = N / 3;
-                    if (n < d) {
-                        a.out[(long)row * a.ldo + n] = v * a.qk_scale;
-                    } else {
-                        const long off = ((long)a.d_slot[row] * a.n_text_ctx + a.d_pos[row]) * d;
-                        if (n < 2 * d) store_kv((KVT *)a.kcache + off + (n - d), v * a.qk_scale);
-                        else store_kv((KVT *)a.vcache + off + (n - 2 * d), v);
-                    }
-                } else {
-                    v *= a.out_scale;
-                    if (a.act == ACT_GELU) v = gelu_f(v);
-                    if (a.R) v += a.R[(long)row * a.ldo + n];
-                    a.out[(long)row * a.ldo + n] = v;
-                }
+        for (int b = 0; b < NB; ++b) {
+            const float v = wave_sum(acc[r][b]);
+            if (lane == r * NB + b) mine = v;
+        }
+    if (my_out) {
+        const int n = n_base + my_r, row = row0 + my_b;
+        float v = mine + my_bias;
+        if (a.qkv) {
+            const int d = N / 3;
+            if (n < d) {
+                a.out[(long)row * a.ldo + n] = v * a.qk_scale;
+            } else {
+                const long off = ((long)a.d_slot[row] * a.n_text_ctx + a.d_pos[row]) * d;
+                if (n < 2 * d) store_kv((KVT *)a.kcache + off + (n - d), v * a.qk_scale);
+                else store_kv((KVT *)a.vcache + off + (n - 2 * d), v);
             }
+        } else {
+            v *= a.out_scale;
+            if (a.act == ACT_GELU) v = gelu_f(v);
+            if (a.R) v += my_res;
+            a.out[(long)row * a.ldo + n] = v;
         }
     }
 }
@@ -440,32 +557,40 @@ __global__ __launch_bounds__(256) void kv_reorder_kernel(const int *__restrict__
         new_idx[j * n_text_ctx + p] = p < n_past ? old_idx[s * n_text_ctx + p] : j;
 }
 
+// rows-per-wave R is a property of the projection class: more output features per wave once N is large
+template <int TAG> struct TagR { static constexpr int v = (TAG == GEMV_LOGITS) ? 4 : ((TAG == GEMV_QKV || TAG == GEMV_FC1) ? 2 : 1); };
+
+template <typename WT, typename KVT, int NB, int TAG>
+void gemv_launch(const GemvArgs &a, int row0, int KC, hipStream_t st) {
+    constexpr int R = TagR<TAG>::v;
+    const size_t lds = (size_t)NB * KC * sizeof(float) * (TAG == GEMV_FC2 ? 2 : 1);
+    dim3 grid(ceil_div(a.N, 4 * R));
+    hipLaunchKernelGGL((gemv_kernel<WT, KVT, NB, R, TAG>), grid, dim3(256), lds, st, a, row0);
+}
+
 template <typename WT, typename KVT, int NB>
-void gemv_dispatch_r(const GemvArgs &a, int row0, int KC, int R, hipStream_t st) {
-    const size_t lds = (size_t)NB * KC * sizeof(float);
-    if (R == 1) {
-        dim3 grid(ceil_div(a.N, 4));
-        hipLaunchKernelGGL((gemv_kernel<WT, KVT, NB, 1>), grid, dim3(256), lds, st, a, row0, KC);
-    } else if (R == 2) {
-        dim3 grid(ceil_div(a.N, 8));
-        hipLaunchKernelGGL((gemv_kernel<WT, KVT, NB, 2>), grid, dim3(256), lds, st, a, row0, KC);
-    } else {
-        dim3 grid(ceil_div(a.N, 16));
-        hipLaunchKernelGGL((gemv_kernel<WT, KVT, NB, 4>), grid, dim3(256), lds, st, a, row0, KC);
+void gemv_dispatch_tag(const GemvArgs &a, int row0, int KC, hipStream_t st) {
+    switch (a.tag) {
+        case GEMV_QKV: gemv_launch<WT, KVT, NB, GEMV_QKV>(a, row0, KC, st); break;
+        case GEMV_ATTN_OUT: gemv_launch<WT, KVT, NB, GEMV_ATTN_OUT>(a, row0, KC, st); break;
+        case GEMV_CROSS_Q: gemv_launch<WT, KVT, NB, GEMV_CROSS_Q>(a, row0, KC, st); break;
+        case GEMV_FC1: gemv_launch<WT, KVT, NB, GEMV_FC1>(a, row0, KC, st); break;
+        case GEMV_FC2: gemv_launch<WT, KVT, NB, GEMV_FC2>(a, row0, KC, st); break;
+        default: gemv_launch<WT, KVT, NB, GEMV_LOGITS>(a, row0, KC, st); break;
     }
 }
 
 template <typename WT, typename KVT>
-void gemv_dispatch(const GemvArgs &a, int row0, int nb, int KC, int R, hipStream_t st) {
+void gemv_dispatch(const GemvArgs &a, int row0, int nb, int KC, hipStream_t st) {
     switch (nb) {
-        case 1: gemv_dispatch_r<WT, KVT, 1>(a, row0, KC, R, st); break;
-        case 2: gemv_dispatch_r<WT, KVT, 2>(a, row0, KC, R, st); break;
-        case 3: gemv_dispatch_r<WT, KVT, 3>(a, row0, KC, R, st); break;
-        case 4: gemv_dispatch_r<WT, KVT, 4>(a, row0, KC, R, st); break;
-        case 5: gemv_dispatch_r<WT, KVT, 5>(a, row0, KC, R, st); break;
-        case 6: gemv_dispatch_r<WT, KVT, 6>(a, row0, KC, R, st); break;
-        case 7: gemv_dispatch_r<WT, KVT, 7>(a, row0, KC, R, st); break;
-        default: gemv_dispatch_r<WT, KVT, 8>(a, row0, KC, R, st); break;
+        case 1: gemv_dispatch_tag<WT, KVT, 1>(a, row0, KC, st); break;
+        case 2: gemv_dispatch_tag<WT, KVT, 2>(a, row0, KC, st); break;
+        case 3: gemv_dispatch_tag<WT, KVT, 3>(a, row0, KC, st); break;
+        case 4: gemv_dispatch_tag<WT, KVT, 4>(a, row0, KC, st); break;
+        case 5: gemv_dispatch_tag<WT, KVT, 5>(a, row0, KC, st); break;
+        case 6: gemv_dispatch_tag<WT, KVT, 6>(a, row0, KC, st); break;
+        case 7: gemv_dispatch_tag<WT, KVT, 7>(a, row0, KC, st); break;
+        default: gemv_dispatch_tag<WT, KVT, 8>(a, row0, KC, st); break;
     }
 }
 
@@ -518,30 +643,22 @@ void launch_embed(const int *d_tokens, const int *d_pos, const void *tok_emb, DT
 void launch_gemv(const GemvArgs &a, DType wt, hipStream_t st) {
     MW_CHECK(a.x && a.W && a.out && a.n > 0 && a.N > 0 && a.K > 0, "gemv: bad arguments");
     const int epc = wt == DType::F32 ? 4 : 8;
-    // activation chunk held in LDS: the model width for K = d or 4d, capped at 1280 floats per row
-    int KC = a.K;
-    if (KC > 1280) {
-        KC = 0;
-        for (int c = 1280; c >= 64; c -= 64)
-            if (a.K % c == 0) {
-                KC = c;
-                break;
-            }
-        MW_CHECK(KC > 0, "gemv: K has no chunk size <= 1280 that is a multiple of 64");
-    }
-    MW_CHECK(KC % (2 * epc) == 0 && a.K % KC == 0, "gemv: K must be a multiple of 16 elements");
+    // K-chunking is a property of the class (GemvShape): single chunk of K <= 1280, or 1024-chunks for FC2
+    const int KC = a.tag == GEMV_FC2 ? 1024 : a.K;
+    if (a.tag == GEMV_FC2) MW_CHECK(a.K <= 5 * 1024, "gemv: FC2 needs K <= 5120");
+    else MW_CHECK(a.K <= 1280, "gemv: this projection class needs K <= 1280");
+    MW_CHECK(a.K % (2 * epc) == 0 && a.K % 64 == 0, "gemv: K must be a multiple of 64");
     MW_CHECK(((uintptr_t)a.W % 16) == 0 && ((uintptr_t)a.x % 16) == 0 && a.ldx % 4 == 0, "gemv: alignment");
-    if (a.ln_w) MW_CHECK(a.K == KC && a.ln_b, "gemv: fused LayerNorm needs K <= 1280");
+    if (a.ln_w) MW_CHECK(a.tag != GEMV_FC2 && a.ln_b, "gemv: fused LayerNorm needs a single-chunk class");
     if (a.qkv) {
         MW_CHECK(a.N % 3 == 0 && a.kcache && a.vcache && a.d_slot && a.d_pos && a.n_text_ctx > 0, "gemv: qkv epilogue");
         MW_CHECK(a.kv_t == wt, "gemv: KV cache type must equal the weight type");
     }
-    // rows per wave: enough workgroups to cover 256 CUs, more rows per wave once N is large
-    const int R = a.N >= 16384 ? 4 : (a.N >= 2560 ? 2 : 1);
+    MW_CHECK(a.tag >= 0 && a.tag < GEMV_N_TAGS, "gemv: bad projection class");
     for (int row0 = 0; row0 < a.n; row0 += DEC_MAX_ROWS) {
         const int nb = std::min(DEC_MAX_ROWS, a.n - row0);
-        if (wt == DType::F32) gemv_dispatch<float, float>(a, row0, nb, KC, R, st);
-        else gemv_dispatch<bf16_t, bf16_t>(a, row0, nb, KC, R, st);
+        if (wt == DType::F32) gemv_dispatch<float, float>(a, row0, nb, KC, st);
+        else gemv_dispatch<bf16_t, bf16_t>(a, row0, nb, KC, st);
     }
     MW_HIP(hipGetLastError());
 }

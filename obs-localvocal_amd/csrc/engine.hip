@@ -41,6 +41,8 @@ Context::~Context() {
     if (h_ints) (void)hipHostFree(h_ints);
     if (h_row_state) (void)hipHostFree(h_row_state);
     if (h_row_res) (void)hipHostFree(h_row_res);
+    for (hipEvent_t e : prof_ev) (void)hipEventDestroy(e);
+    for (auto &kv : graphs) (void)hipGraphExecDestroy(kv.second);
     if (st) (void)hipStreamDestroy(st);
 }
 
@@ -104,6 +106,7 @@ std::unique_ptr<Context> create_context(const unsigned char *data, size_t size, 
     MW_HIP(hipHostMalloc((void **)&c->h_row_res, LOGIT_ROWS * sizeof(LogitsRowResult)));
     c->decoders[0].rng = std::mt19937(0);
     c->n_ctx_cur = (int)T;
+    if (getenv("MI355_WHISPER_NO_GRAPH")) c->use_graphs = false;  // debugging aid: eager launches
     MW_HIP(hipStreamSynchronize(c->st));
     log_msg(LOG_INFO, "mi355_whisper: model loaded (%zu params, %s weights, %.1f MB arena) on device %d (%s)\n",
             c->model.n_params, wt == DType::F32 ? "fp32" : "bf16", c->model.arena_used / 1048576.0, device,
@@ -289,66 +292,108 @@ void decode(Context &c, const int *tokens, const int *pos, const int *slot, int 
     memcpy(hi + TC, pos, n * sizeof(int));
     memcpy(hi + 2 * TC, slot, n * sizeof(int));
     memcpy(hi + 3 * TC, logit_rows, n_logit_rows * sizeof(int));
-    MW_HIP(hipMemcpyAsync(c.d_tokens, hi, n * sizeof(int), hipMemcpyHostToDevice, st));
-    MW_HIP(hipMemcpyAsync(c.d_pos, hi + TC, n * sizeof(int), hipMemcpyHostToDevice, st));
-    MW_HIP(hipMemcpyAsync(c.d_slot, hi + 2 * TC, n * sizeof(int), hipMemcpyHostToDevice, st));
-    if (n_logit_rows)
-        MW_HIP(hipMemcpyAsync(c.d_rows, hi + 3 * TC, n_logit_rows * sizeof(int), hipMemcpyHostToDevice, st));
-    launch_embed(c.d_tokens, c.d_pos, m.tok_emb, wt, m.dec_pe, c.d_xd, n, d, st);
-    const float qk_scale = powf(64.0f, -0.25f);
-    const int splits = std::min(CROSS_SPLITS_MAX, std::max(ceil_div(n_ctx, 256), ceil_div(n_ctx, 128)));
-    const size_t kv_layer = (size_t)KV_SLOTS * TC * d * ws;
-    for (int l = 0; l < hp.n_text_layer; ++l) {
-        const DecLayer &e = m.dec[l];
-        {
-            GemvArgs g;  // LN + Q|K|V; K and V go straight into the cache
-            g.x = c.d_xd; g.ldx = d; g.n = n; g.W = e.qkv_w; g.bias = e.qkv_b; g.N = 3 * d; g.K = d;
-            g.ln_w = e.ln1_w; g.ln_b = e.ln1_b; g.out = c.d_q; g.ldo = d; g.qkv = 1; g.qk_scale = qk_scale;
-            g.kcache = (char *)c.d_kself + l * kv_layer; g.vcache = (char *)c.d_vself + l * kv_layer;
-            g.kv_t = wt; g.d_slot = c.d_slot; g.d_pos = c.d_pos; g.n_text_ctx = TC;
+    // Everything below is one fixed launch sequence for a given (rows, logits rows, index table, audio
+    // context): it is captured into a hipGraph once and replayed, because the step is launch-bound
+    // (~290 launches of 3-10 us kernels).  Per-step values (tokens, positions, slots) travel through
+    // the pinned staging block and device arrays at fixed addresses, so the captured nodes stay valid.
+    auto enqueue = [&]() {
+        MW_HIP(hipMemcpyAsync(c.d_tokens, hi, n * sizeof(int), hipMemcpyHostToDevice, st));
+        MW_HIP(hipMemcpyAsync(c.d_pos, hi + TC, n * sizeof(int), hipMemcpyHostToDevice, st));
+        MW_HIP(hipMemcpyAsync(c.d_slot, hi + 2 * TC, n * sizeof(int), hipMemcpyHostToDevice, st));
+        if (n_logit_rows)
+            MW_HIP(hipMemcpyAsync(c.d_rows, hi + 3 * TC, n_logit_rows * sizeof(int), hipMemcpyHostToDevice, st));
+        // launches of the profiled projection class are bracketed by HIP events (mw_profile_begin/end)
+        auto gemv = [&](const GemvArgs &g) {
+            const bool prof = g.tag == c.prof_tag && c.prof_n + 2 <= (int)c.prof_ev.size();
+            if (prof) MW_HIP(hipEventRecord(c.prof_ev[c.prof_n++], st));
             launch_gemv(g, wt, st);
+            if (prof) MW_HIP(hipEventRecord(c.prof_ev[c.prof_n++], st));
+        };
+        launch_embed(c.d_tokens, c.d_pos, m.tok_emb, wt, m.dec_pe, c.d_xd, n, d, st);
+        const float qk_scale = powf(64.0f, -0.25f);
+        const int splits = std::min(CROSS_SPLITS_MAX, std::max(ceil_div(n_ctx, 256), ceil_div(n_ctx, 128)));
+        const size_t kv_layer = (size_t)KV_SLOTS * TC * d * ws;
+        for (int l = 0; l < hp.n_text_layer; ++l) {
+            const DecLayer &e = m.dec[l];
+            {
+                GemvArgs g;  // LN + Q|K|V; K and V go straight into the cache
+                g.x = c.d_xd; g.ldx = d; g.n = n; g.W = e.qkv_w; g.bias = e.qkv_b; g.N = 3 * d; g.K = d;
+                g.ln_w = e.ln1_w; g.ln_b = e.ln1_b; g.out = c.d_q; g.ldo = d; g.qkv = 1; g.qk_scale = qk_scale;
+                g.kcache = (char *)c.d_kself + l * kv_layer; g.vcache = (char *)c.d_vself + l * kv_layer;
+                g.kv_t = wt; g.d_slot = c.d_slot; g.d_pos = c.d_pos; g.n_text_ctx = TC; g.tag = GEMV_QKV;
+                gemv(g);
+            }
+            launch_self_attn(c.d_q, (char *)c.d_kself + l * kv_layer, (char *)c.d_vself + l * kv_layer, wt, c.d_slot, c.d_pos,
+                             c.d_kv_idx[c.kv_cur], c.d_attd, n, H, d, TC, st);
+            {
+                GemvArgs g;
+                g.x = c.d_attd; g.ldx = d; g.n = n; g.W = e.out_w; g.bias = e.out_b; g.N = d; g.K = d;
+                g.out = c.d_xd; g.ldo = d; g.R = c.d_xd; g.tag = GEMV_ATTN_OUT;
+                gemv(g);
+            }
+            {
+                GemvArgs g;  // LN + cross query (scaled)
+                g.x = c.d_xd; g.ldx = d; g.n = n; g.W = e.cq_w; g.bias = e.cq_b; g.N = d; g.K = d;
+                g.ln_w = e.lnc_w; g.ln_b = e.lnc_b; g.out = c.d_q; g.ldo = d; g.out_scale = qk_scale; g.tag = GEMV_CROSS_Q;
+                gemv(g);
+            }
+            const char *ck = (const char *)c.d_cross + (size_t)l * 2 * hp.n_audio_ctx * d * ws;
+            launch_cross_attn(c.d_q, ck, ck + (size_t)hp.n_audio_ctx * d * ws, wt, c.d_part, c.d_attd, n, H, d, n_ctx, splits,
+                              st);
+            {
+                GemvArgs g;
+                g.x = c.d_attd; g.ldx = d; g.n = n; g.W = e.co_w; g.bias = e.co_b; g.N = d; g.K = d;
+                g.out = c.d_xd; g.ldo = d; g.R = c.d_xd; g.tag = GEMV_ATTN_OUT;
+                gemv(g);
+            }
+            {
+                GemvArgs g;
+                g.x = c.d_xd; g.ldx = d; g.n = n; g.W = e.fc1_w; g.bias = e.fc1_b; g.N = 4 * d; g.K = d;
+                g.ln_w = e.ln2_w; g.ln_b = e.ln2_b; g.act = ACT_GELU; g.out = c.d_ffd; g.ldo = 4 * d; g.tag = GEMV_FC1;
+                gemv(g);
+            }
+            {
+                GemvArgs g;
+                g.x = c.d_ffd; g.ldx = 4 * d; g.n = n; g.W = e.fc2_w; g.bias = e.fc2_b; g.N = d; g.K = 4 * d;
+                g.out = c.d_xd; g.ldo = d; g.R = c.d_xd; g.tag = GEMV_FC2;
+                gemv(g);
+            }
         }
-        launch_self_attn(c.d_q, (char *)c.d_kself + l * kv_layer, (char *)c.d_vself + l * kv_layer, wt, c.d_slot, c.d_pos,
-                         c.d_kv_idx[c.kv_cur], c.d_attd, n, H, d, TC, st);
-        {
-            GemvArgs g;
-            g.x = c.d_attd; g.ldx = d; g.n = n; g.W = e.out_w; g.bias = e.out_b; g.N = d; g.K = d;
-            g.out = c.d_xd; g.ldo = d; g.R = c.d_xd;
-            launch_gemv(g, wt, st);
+        if (n_logit_rows > 0) {
+            GemvArgs g;  // final LN + tied-embedding logits, only for the rows that are sampled from
+            g.x = c.d_xd; g.ldx = d; g.n = n_logit_rows; g.W = m.tok_emb; g.N = hp.n_vocab; g.K = d;
+            g.ln_w = m.dec_ln_w; g.ln_b = m.dec_ln_b; g.out = c.d_logits; g.ldo = hp.n_vocab; g.d_rows = c.d_rows;
+            g.tag = GEMV_LOGITS;
+            gemv(g);
         }
-        {
-            GemvArgs g;  // LN + cross query (scaled)
-            g.x = c.d_xd; g.ldx = d; g.n = n; g.W = e.cq_w; g.bias = e.cq_b; g.N = d; g.K = d;
-            g.ln_w = e.lnc_w; g.ln_b = e.lnc_b; g.out = c.d_q; g.ldo = d; g.out_scale = qk_scale;
-            launch_gemv(g, wt, st);
+    };
+    const bool use_graph = c.use_graphs && c.prof_tag < 0;
+    if (!use_graph) {
+        enqueue();
+    } else {
+        const uint64_t key = ((uint64_t)n << 40) | ((uint64_t)n_logit_rows << 24) | ((uint64_t)n_ctx << 4) | (uint64_t)c.kv_cur;
+        auto it = c.graphs.find(key);
+        if (it == c.graphs.end()) {
+            if (c.graphs.size() >= 96) {  // bounded cache (prompt lengths vary)
+                for (auto &kv : c.graphs) (void)hipGraphExecDestroy(kv.second);
+                c.graphs.clear();
+            }
+            hipGraph_t graph = nullptr;
+            MW_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            try {
+                enqueue();
+            } catch (...) {
+                (void)hipStreamEndCapture(st, &graph);
+                if (graph) (void)hipGraphDestroy(graph);
+                throw;
+            }
+            MW_HIP(hipStreamEndCapture(st, &graph));
+            hipGraphExec_t exec = nullptr;
+            MW_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+            MW_HIP(hipGraphDestroy(graph));
+            it = c.graphs.emplace(key, exec).first;
         }
-        const char *ck = (const char *)c.d_cross + (size_t)l * 2 * hp.n_audio_ctx * d * ws;
-        launch_cross_attn(c.d_q, ck, ck + (size_t)hp.n_audio_ctx * d * ws, wt, c.d_part, c.d_attd, n, H, d, n_ctx, splits,
-                          st);
-        {
-            GemvArgs g;
-            g.x = c.d_attd; g.ldx = d; g.n = n; g.W = e.co_w; g.bias = e.co_b; g.N = d; g.K = d;
-            g.out = c.d_xd; g.ldo = d; g.R = c.d_xd;
-            launch_gemv(g, wt, st);
-        }
-        {
-            GemvArgs g;
-            g.x = c.d_xd; g.ldx = d; g.n = n; g.W = e.fc1_w; g.bias = e.fc1_b; g.N = 4 * d; g.K = d;
-            g.ln_w = e.ln2_w; g.ln_b = e.ln2_b; g.act = ACT_GELU; g.out = c.d_ffd; g.ldo = 4 * d;
-            launch_gemv(g, wt, st);
-        }
-        {
-            GemvArgs g;
-            g.x = c.d_ffd; g.ldx = 4 * d; g.n = n; g.W = e.fc2_w; g.bias = e.fc2_b; g.N = d; g.K = 4 * d;
-            g.out = c.d_xd; g.ldo = d; g.R = c.d_xd;
-            launch_gemv(g, wt, st);
-        }
-    }
-    if (n_logit_rows > 0) {
-        GemvArgs g;  // final LN + tied-embedding logits, only for the rows that are sampled from
-        g.x = c.d_xd; g.ldx = d; g.n = n_logit_rows; g.W = m.tok_emb; g.N = hp.n_vocab; g.K = d;
-        g.ln_w = m.dec_ln_w; g.ln_b = m.dec_ln_b; g.out = c.d_logits; g.ldo = hp.n_vocab; g.d_rows = c.d_rows;
-        launch_gemv(g, wt, st);
+        MW_HIP(hipGraphLaunch(it->second, st));
     }
     c.n_logit_rows = n_logit_rows;
     c.tm.n_decode++;
@@ -525,7 +570,7 @@ int lang_auto_detect(Context &c, int offset_ms, float *lang_probs) {
 // ------------------------------------------------------------------------------------------
 // whisper_full (A.6)
 // ------------------------------------------------------------------------------------------
-int full(Context &c, whisper_full_params params, const float *samples, int n_samples) {
+int full(Context &c, whisper_full_params params, const float *samples, int n_samples, bool samples_on_device) {
     const Model &model = c.model;
     const Vocab &vocab = model.vocab;
     const HParams &hp = model.hp;
@@ -533,7 +578,7 @@ int full(Context &c, whisper_full_params params, const float *samples, int n_sam
     if (params.logits_filter_callback || params.grammar_rules) return -10;
     auto &result_all = c.result_all;
     result_all.clear();
-    if (n_samples > 0) pcm_to_mel(c, samples, n_samples, false);
+    if (n_samples > 0) pcm_to_mel(c, samples, n_samples, samples_on_device);
     if (c.d_mel == nullptr) return -2;
     std::string language = params.language ? params.language : "";
     if (language.empty() || language == "auto" || params.detect_language) {

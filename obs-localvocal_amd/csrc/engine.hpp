@@ -82,6 +82,12 @@ struct Context {
     int force_decode_steps = 0;  // bench-only extension (mw_set_force_decode_steps)
     std::string suppress_key;    // cache key of the uploaded suppression mask
     Timings tm;
+    // live per-kernel timing of one projection class (bench.py roofline leg)
+    int prof_tag = -1, prof_n = 0;
+    std::vector<hipEvent_t> prof_ev;
+    // captured decode steps, keyed by (rows, logits rows, audio ctx, index-table parity)
+    bool use_graphs = true;
+    std::unordered_map<uint64_t, hipGraphExec_t> graphs;
 
     ~Context();
 };
@@ -97,7 +103,7 @@ void decode(Context &c, const int *tokens, const int *pos, const int *slot, int 
 void kv_clear(Context &c);
 void kv_reorder(Context &c, const int *src /*[MAX_DECODERS]*/, int n_past);
 int lang_auto_detect(Context &c, int offset_ms, float *probs);
-int full(Context &c, whisper_full_params params, const float *samples, int n_samples);
+int full(Context &c, whisper_full_params params, const float *samples, int n_samples, bool samples_on_device = false);
 // builds + uploads the static suppression mask for these params (cached)
 void upload_suppress_mask(Context &c, const whisper_full_params &params);
 LogitsParams make_logits_params(const Context &c, const whisper_full_params &params, float temperature, int n_samples);

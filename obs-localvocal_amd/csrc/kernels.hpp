@@ -87,7 +87,11 @@ constexpr int CROSS_SPLITS_MAX = 16;
 void launch_embed(const int *d_tokens, const int *d_pos, const void *tok_emb, DType wt, const float *pos_emb,
                   float *x, int n, int d, hipStream_t st);
 
+// projection classes of the decode step (each is a distinct kernel symbol)
+enum { GEMV_QKV = 0, GEMV_ATTN_OUT = 1, GEMV_CROSS_Q = 2, GEMV_FC1 = 3, GEMV_FC2 = 4, GEMV_LOGITS = 5, GEMV_N_TAGS = 6 };
+
 struct GemvArgs {
+    int tag = GEMV_ATTN_OUT;
     const float *x = nullptr;  // [n][K] f32 activations (row stride ldx)
     long ldx = 0;
     int n = 0;                 // rows (any count; processed DEC_MAX_ROWS at a time)
