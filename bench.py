@@ -170,9 +170,8 @@ def main():
     elapsed = time.perf_counter() - t0
     tm = eng.timings()
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        from tools import stream_shard
+        elapsed = stream_shard.max_over_ranks(dist, elapsed, device=f"cuda:{local_rank}")
 
     # roofline leg: the same step, launch by launch (graphs off while a projection class is bracketed by
     # HIP events on the engine's stream), right after the timed region, same process, same weights

@@ -1,0 +1,61 @@
+"""CPU, world_size 2 over gloo: the N>1 path of bench.py (stream partition + barrier + MAX-reduced time)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tools import stream_shard
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = stream_shard.assign_streams(7, world, rank)
+    dist.barrier()
+    elapsed = 1.0 + rank  # rank 1 is the slow one
+    mx = stream_shard.max_over_ranks(dist, elapsed)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    q.put((rank, mine, mx, gathered))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_partition_and_time_reduce():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res.sort()
+    assert res[0][1] == [0, 2, 4, 6] and res[1][1] == [1, 3, 5]
+    assert all(r[2] == 2.0 for r in res)                       # MAX over ranks
+    allstreams = sorted(s for part in res[0][3] for s in part)
+    assert allstreams == list(range(7))                         # every stream exactly once, no overlap
+    assert stream_shard.aggregate_throughput(30.0 * 8, world, 2.0) == 240.0
+
+
+def test_assign_streams_edges():
+    assert stream_shard.assign_streams(0, 4, 1) == []
+    assert stream_shard.assign_streams(3, 8, 5) == []
+    assert stream_shard.assign_streams(64, 8, 7) == list(range(7, 64, 8))
+    import pytest
+    with pytest.raises(ValueError):
+        stream_shard.assign_streams(4, 2, 2)
