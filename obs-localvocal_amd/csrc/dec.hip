@@ -320,11 +320,11 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a, int row0) {
 // ------------------------------------------------------------------------------------------
 // self-attention over the indirected KV cache: one wavefront per (row, head), dh = 64
 // ------------------------------------------------------------------------------------------
-template <typename KVT>
+template <typename KVT, typename OT>
 __global__ __launch_bounds__(64) void self_attn_kernel(const float *__restrict__ q, const KVT *__restrict__ kc,
                                                        const KVT *__restrict__ vc, const int *__restrict__ slot,
                                                        const int *__restrict__ pos, const int *__restrict__ kv_idx,
-                                                       float *__restrict__ out, int d, int n_text_ctx) {
+                                                       OT *__restrict__ out, int d, int n_text_ctx) {
     constexpr int EPC = Epc<KVT>::v;
     constexpr int NCH = 64 / EPC;  // 16-byte chunks per head row
     constexpr int MAXIT = 7;       // 7 * 64 = 448 positions
@@ -402,9 +402,9 @@ __global__ __launch_bounds__(64) void self_attn_kernel(const float *__restrict__
         o[e] += __shfl_xor(o[e], 32);
     }
     if (jj == 0) {
-        float *op = out + (long)i * d + h * 64 + e8 * 8;
+        OT *op = out + (long)i * d + h * 64 + e8 * 8;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) op[e] = o[e] * inv;
+        for (int e = 0; e < 8; ++e) store_kv(op + e, o[e] * inv);
     }
 }
 
@@ -532,7 +532,8 @@ __global__ __launch_bounds__(256) void cross_attn_kernel(const float *__restrict
     }
 }
 
-__global__ __launch_bounds__(64) void cross_combine_kernel(const float *__restrict__ part, float *__restrict__ out,
+template <typename OT>
+__global__ __launch_bounds__(64) void cross_combine_kernel(const float *__restrict__ part, OT *__restrict__ out,
                                                            int H, int d, int splits) {
     const int h = blockIdx.x, i = blockIdx.y, e = threadIdx.x;
     const float *pp = part + ((long)i * H + h) * splits * CROSS_PART;
@@ -545,7 +546,7 @@ __global__ __launch_bounds__(64) void cross_combine_kernel(const float *__restri
         L += w * pp[s * CROSS_PART + 1];
         o += w * pp[s * CROSS_PART + 2 + e];
     }
-    out[(long)i * d + h * 64 + e] = o / L;
+    store_kv(out + (long)i * d + h * 64 + e, o / L);
 }
 
 __global__ __launch_bounds__(256) void kv_reorder_kernel(const int *__restrict__ old_idx, int *__restrict__ new_idx,
@@ -664,29 +665,36 @@ void launch_gemv(const GemvArgs &a, DType wt, hipStream_t st) {
 }
 
 void launch_self_attn(const float *q, const void *kcache, const void *vcache, DType kv_t, const int *d_slot,
-                      const int *d_pos, const int *d_kv_idx, float *out, int n, int H, int d, int n_text_ctx,
+                      const int *d_pos, const int *d_kv_idx, void *out, DType out_t, int n, int H, int d, int n_text_ctx,
                       hipStream_t st) {
     MW_CHECK(n > 0 && H > 0 && d == H * 64, "self-attn: head size must be 64");
     MW_CHECK(n_text_ctx <= 448, "self-attn: n_text_ctx > 448");
     dim3 grid(H, n);
+    MW_CHECK(kv_t == out_t || out_t == DType::F32, "self-attn: output type");
     if (kv_t == DType::F32)
-        hipLaunchKernelGGL(self_attn_kernel<float>, grid, dim3(64), 0, st, q, (const float *)kcache, (const float *)vcache,
-                           d_slot, d_pos, d_kv_idx, out, d, n_text_ctx);
+        hipLaunchKernelGGL((self_attn_kernel<float, float>), grid, dim3(64), 0, st, q, (const float *)kcache,
+                           (const float *)vcache, d_slot, d_pos, d_kv_idx, (float *)out, d, n_text_ctx);
+    else if (out_t == DType::F32)
+        hipLaunchKernelGGL((self_attn_kernel<bf16_t, float>), grid, dim3(64), 0, st, q, (const bf16_t *)kcache,
+                           (const bf16_t *)vcache, d_slot, d_pos, d_kv_idx, (float *)out, d, n_text_ctx);
     else
-        hipLaunchKernelGGL(self_attn_kernel<bf16_t>, grid, dim3(64), 0, st, q, (const bf16_t *)kcache,
-                           (const bf16_t *)vcache, d_slot, d_pos, d_kv_idx, out, d, n_text_ctx);
+        hipLaunchKernelGGL((self_attn_kernel<bf16_t, bf16_t>), grid, dim3(64), 0, st, q, (const bf16_t *)kcache,
+                           (const bf16_t *)vcache, d_slot, d_pos, d_kv_idx, (bf16_t *)out, d, n_text_ctx);
     MW_HIP(hipGetLastError());
 }
 
-void launch_cross_attn(const float *q, const void *kc, const void *vc, DType kv_t, float *partial, float *out, int n,
-                       int H, int d, int n_ctx, int splits, hipStream_t st) {
+void launch_cross_attn(const float *q, const void *kc, const void *vc, DType kv_t, float *partial, void *out, DType out_t,
+                       int n, int H, int d, int n_ctx, int splits, hipStream_t st) {
     MW_CHECK(n > 0 && H > 0 && d == H * 64 && n_ctx > 0, "cross-attn: head size must be 64");
     MW_CHECK(splits >= 1 && splits <= CROSS_SPLITS_MAX, "cross-attn: split count");
     const int per = ceil_div(n_ctx, splits);
     MW_CHECK(per <= 256, "cross-attn: more than 256 keys per split");
     if (kv_t == DType::F32) cross_dispatch<float>(q, kc, vc, partial, n, H, d, n_ctx, splits, per, st);
     else cross_dispatch<bf16_t>(q, kc, vc, partial, n, H, d, n_ctx, splits, per, st);
-    hipLaunchKernelGGL(cross_combine_kernel, dim3(H, n), dim3(64), 0, st, partial, out, H, d, splits);
+    if (out_t == DType::F32)
+        hipLaunchKernelGGL(cross_combine_kernel<float>, dim3(H, n), dim3(64), 0, st, partial, (float *)out, H, d, splits);
+    else
+        hipLaunchKernelGGL(cross_combine_kernel<bf16_t>, dim3(H, n), dim3(64), 0, st, partial, (bf16_t *)out, H, d, splits);
     MW_HIP(hipGetLastError());
 }
 

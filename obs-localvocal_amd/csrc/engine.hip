@@ -93,8 +93,8 @@ std::unique_ptr<Context> create_context(const unsigned char *data, size_t size, 
     dev_alloc(c->d_rows, TC);
     dev_alloc(c->d_xd, TC * d);
     dev_alloc(c->d_q, TC * d);
-    dev_alloc(c->d_attd, TC * d);
-    dev_alloc(c->d_ffd, TC * 4 * d);
+    dev_alloc_bytes(c->d_attd, TC * d * 4);
+    dev_alloc_bytes(c->d_ffd, TC * 4 * d * 4);
     dev_alloc(c->d_part, TC * H * CROSS_SPLITS_MAX * 66);
     dev_alloc(c->d_logits, (size_t)LOGIT_ROWS * nv);
     dev_alloc(c->d_work, (size_t)LOGIT_ROWS * nv);
@@ -107,6 +107,9 @@ std::unique_ptr<Context> create_context(const unsigned char *data, size_t size, 
     c->decoders[0].rng = std::mt19937(0);
     c->n_ctx_cur = (int)T;
     if (getenv("MI355_WHISPER_NO_GRAPH")) c->use_graphs = false;  // debugging aid: eager launches
+    // the matrix-core projection variant measured ~5 % slower per window than the VALU one at 5 rows
+    // (profiles/r01_*): kept selectable for wider batches
+    c->mfma_proj = wt == DType::BF16 && getenv("MI355_WHISPER_MFMA_PROJ") != nullptr;
     MW_HIP(hipStreamSynchronize(c->st));
     log_msg(LOG_INFO, "mi355_whisper: model loaded (%zu params, %s weights, %.1f MB arena) on device %d (%s)\n",
             c->model.n_params, wt == DType::F32 ? "fp32" : "bf16", c->model.arena_used / 1048576.0, device,
@@ -284,6 +287,8 @@ void decode(Context &c, const int *tokens, const int *pos, const int *slot, int 
     }
     for (int i = 0; i < n_logit_rows; ++i) MW_CHECK(logit_rows[i] >= 0 && logit_rows[i] < n, "decode: bad logits row");
     hipStream_t st = c.st;
+    const bool mf = c.mfma_proj;  // bf16 rows between attention / MLP kernels and the projections
+    const DType act_t = mf ? DType::BF16 : DType::F32;
     const double t0 = now_ms();
     // the pinned staging block may still be read by the previous call's copies
     MW_HIP(hipStreamSynchronize(st));
@@ -306,7 +311,8 @@ void decode(Context &c, const int *tokens, const int *pos, const int *slot, int 
         auto gemv = [&](const GemvArgs &g) {
             const bool prof = g.tag == c.prof_tag && c.prof_n + 2 <= (int)c.prof_ev.size();
             if (prof) MW_HIP(hipEventRecord(c.prof_ev[c.prof_n++], st));
-            launch_gemv(g, wt, st);
+            if (mf) launch_gemv_mfma(g, st);  // matrix-core variant (dec_mfma.hip), opt-in
+            else launch_gemv(g, wt, st);      // VALU weight-streaming path (dec.hip)
             if (prof) MW_HIP(hipEventRecord(c.prof_ev[c.prof_n++], st));
         };
         launch_embed(c.d_tokens, c.d_pos, m.tok_emb, wt, m.dec_pe, c.d_xd, n, d, st);
@@ -324,10 +330,10 @@ void decode(Context &c, const int *tokens, const int *pos, const int *slot, int 
                 gemv(g);
             }
             launch_self_attn(c.d_q, (char *)c.d_kself + l * kv_layer, (char *)c.d_vself + l * kv_layer, wt, c.d_slot, c.d_pos,
-                             c.d_kv_idx[c.kv_cur], c.d_attd, n, H, d, TC, st);
+                             c.d_kv_idx[c.kv_cur], c.d_attd, act_t, n, H, d, TC, st);
             {
                 GemvArgs g;
-                g.x = c.d_attd; g.ldx = d; g.n = n; g.W = e.out_w; g.bias = e.out_b; g.N = d; g.K = d;
+                g.x = (const float *)c.d_attd; g.x_bf16 = mf; g.ldx = d; g.n = n; g.W = e.out_w; g.bias = e.out_b; g.N = d; g.K = d;
                 g.out = c.d_xd; g.ldo = d; g.R = c.d_xd; g.tag = GEMV_ATTN_OUT;
                 gemv(g);
             }
@@ -338,23 +344,23 @@ void decode(Context &c, const int *tokens, const int *pos, const int *slot, int 
                 gemv(g);
             }
             const char *ck = (const char *)c.d_cross + (size_t)l * 2 * hp.n_audio_ctx * d * ws;
-            launch_cross_attn(c.d_q, ck, ck + (size_t)hp.n_audio_ctx * d * ws, wt, c.d_part, c.d_attd, n, H, d, n_ctx, splits,
-                              st);
+            launch_cross_attn(c.d_q, ck, ck + (size_t)hp.n_audio_ctx * d * ws, wt, c.d_part, c.d_attd, act_t, n, H, d, n_ctx,
+                              splits, st);
             {
                 GemvArgs g;
-                g.x = c.d_attd; g.ldx = d; g.n = n; g.W = e.co_w; g.bias = e.co_b; g.N = d; g.K = d;
+                g.x = (const float *)c.d_attd; g.x_bf16 = mf; g.ldx = d; g.n = n; g.W = e.co_w; g.bias = e.co_b; g.N = d; g.K = d;
                 g.out = c.d_xd; g.ldo = d; g.R = c.d_xd; g.tag = GEMV_ATTN_OUT;
                 gemv(g);
             }
             {
                 GemvArgs g;
                 g.x = c.d_xd; g.ldx = d; g.n = n; g.W = e.fc1_w; g.bias = e.fc1_b; g.N = 4 * d; g.K = d;
-                g.ln_w = e.ln2_w; g.ln_b = e.ln2_b; g.act = ACT_GELU; g.out = c.d_ffd; g.ldo = 4 * d; g.tag = GEMV_FC1;
+                g.ln_w = e.ln2_w; g.ln_b = e.ln2_b; g.act = ACT_GELU; g.out = (float *)c.d_ffd; g.out_bf16 = mf; g.ldo = 4 * d; g.tag = GEMV_FC1;
                 gemv(g);
             }
             {
                 GemvArgs g;
-                g.x = c.d_ffd; g.ldx = 4 * d; g.n = n; g.W = e.fc2_w; g.bias = e.fc2_b; g.N = d; g.K = 4 * d;
+                g.x = (const float *)c.d_ffd; g.x_bf16 = mf; g.ldx = 4 * d; g.n = n; g.W = e.fc2_w; g.bias = e.fc2_b; g.N = d; g.K = 4 * d;
                 g.out = c.d_xd; g.ldo = d; g.R = c.d_xd; g.tag = GEMV_FC2;
                 gemv(g);
             }

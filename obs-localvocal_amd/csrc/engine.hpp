@@ -63,8 +63,8 @@ struct Context {
     int *d_kv_idx[2] = {nullptr, nullptr};
     int kv_cur = 0;
     int *d_tokens = nullptr, *d_pos = nullptr, *d_slot = nullptr, *d_rows = nullptr;
-    float *d_xd = nullptr, *d_q = nullptr, *d_attd = nullptr, *d_ffd = nullptr, *d_part = nullptr, *d_logits = nullptr,
-          *d_work = nullptr;
+    float *d_xd = nullptr, *d_q = nullptr, *d_part = nullptr, *d_logits = nullptr, *d_work = nullptr;
+    void *d_attd = nullptr, *d_ffd = nullptr;  // attention output / MLP hidden rows (compute type)
     unsigned char *d_suppress = nullptr;
     LogitsRowState *d_row_state = nullptr;
     LogitsRowResult *d_row_res = nullptr;
@@ -87,6 +87,7 @@ struct Context {
     std::vector<hipEvent_t> prof_ev;
     // captured decode steps, keyed by (rows, logits rows, audio ctx, index-table parity)
     bool use_graphs = true;
+    bool mfma_proj = false;  // decode projections on MFMA (bf16 weights only; env MI355_WHISPER_MFMA_PROJ)
     std::unordered_map<uint64_t, hipGraphExec_t> graphs;
 
     ~Context();

@@ -113,17 +113,21 @@ struct GemvArgs {
     const int *d_slot = nullptr, *d_pos = nullptr;
     int n_text_ctx = 0;
     const int *d_rows = nullptr;  // optional row gather: use x row d_rows[i] for output row i
+    // bf16 matrix-core path only (dec_mfma.hip): activations already bf16 (direct classes) / bf16 output
+    int x_bf16 = 0, out_bf16 = 0;
 };
 void launch_gemv(const GemvArgs &a, DType wt, hipStream_t st);
+// bf16 weights, <= 8 rows per pass on v_mfma_f32_16x16x32_bf16 (same contract as launch_gemv)
+void launch_gemv_mfma(const GemvArgs &a, hipStream_t st);
 
 // self-attention of n query rows over the indirected cache: row i attends positions 0..pos[i] of
 // logical sequence slot[i]; position p of sequence s lives in physical slot kv_idx[s][p].
 void launch_self_attn(const float *q, const void *kcache, const void *vcache, DType kv_t, const int *d_slot,
-                      const int *d_pos, const int *d_kv_idx, float *out, int n, int H, int d, int n_text_ctx,
+                      const int *d_pos, const int *d_kv_idx, void *out, DType out_t, int n, int H, int d, int n_text_ctx,
                       hipStream_t st);
 // cross-attention of n query rows over the stream's encoder K/V [n_ctx][d]; split over keys
-void launch_cross_attn(const float *q, const void *kc, const void *vc, DType kv_t, float *partial, float *out, int n,
-                       int H, int d, int n_ctx, int splits, hipStream_t st);
+void launch_cross_attn(const float *q, const void *kc, const void *vc, DType kv_t, float *partial, void *out, DType out_t,
+                       int n, int H, int d, int n_ctx, int splits, hipStream_t st);
 // new_idx[j][p] = old_idx[src[j]][p] for p < n_past; new_idx[j][n_past] = j   (beam reshuffle)
 struct BeamSrc {
     int src[KV_SLOTS];

@@ -95,6 +95,24 @@ int main(int argc, char **argv) {
         });
         printf("%-12s N=%5d K=%5d rows=%d : %7.2f us/launch  %7.1f GB/s\n", c.name, c.N, c.K, rows, us, bytes / us / 1e3);
     }
+    // matrix-core path (dec_mfma.hip)
+    unsigned short *xb;
+    hipMalloc(&xb, 8 * 4 * d * 2);
+    hipMemset(xb, 0, 8 * 4 * d * 2);
+    for (const Case &c : cases) {
+        const double bytes = (double)c.N * c.K * 2;
+        const bool direct = c.tag == GEMV_ATTN_OUT || c.tag == GEMV_FC2;
+        float us = time_it(st, 200, [&](int i) {
+            GemvArgs g;
+            g.tag = c.tag; g.x = direct ? (const float *)xb : x; g.x_bf16 = direct; g.ldx = c.K; g.n = rows; g.W = W + per * (i % L); g.bias = bias;
+            g.N = c.N; g.K = c.K; g.out = out; g.ldo = c.tag == GEMV_QKV ? d : c.N;
+            if (c.ln) { g.ln_w = lnw; g.ln_b = lnb; }
+            if (c.res) g.R = out;
+            if (c.tag == GEMV_QKV) { g.qkv = 1; g.kcache = kc; g.vcache = vc; g.kv_t = DType::BF16; g.d_slot = slot; g.d_pos = pos; g.n_text_ctx = 448; }
+            launch_gemv_mfma(g, st);
+        });
+        printf("mfma %-12s N=%5d K=%5d rows=%d : %7.2f us/launch  %7.1f GB/s\n", c.name, c.N, c.K, rows, us, bytes / us / 1e3);
+    }
     // floors
     {
         float us = time_it(st, 200, [&](int i) { hipLaunchKernelGGL((stream_floor<1, 3>), dim3(d / 4), dim3(256), 0, st, W + per * (i % L), d, d, out); });
