@@ -66,6 +66,77 @@ int lv_run_whisper_inference(lv_filter *f, const float *pcm32f_data, size_t pcm3
 /* to_timestamp (whisper-utils.cpp:150-161); writes at most n bytes incl. NUL */
 void lv_to_timestamp(uint64_t t_ms_offset, char *buf, size_t n);
 
+/* ---- the callers of the path: settings, audio tap, segmentation, worker thread ---- */
+
+/* enum VadMode, /root/reference/src/whisper-utils/vad-processing.h:31 */
+enum lv_vad_mode { LV_VAD_MODE_ACTIVE = 0, LV_VAD_MODE_HYBRID, LV_VAD_MODE_DISABLED };
+
+/* obs_data_t stand-in holding the keys of whisper-params.cpp:54-100 ("strategy", "n_threads", ...,
+   "beam_search.patience").  Defaults are installed at lv_filter_create
+   (apply_whisper_params_defaults_on_settings). Setters return 0, or -1 for a null argument. */
+int lv_settings_set_int(lv_filter *f, const char *key, long long v);
+int lv_settings_set_double(lv_filter *f, const char *key, double v);
+int lv_settings_set_bool(lv_filter *f, const char *key, int v);
+int lv_settings_set_string(lv_filter *f, const char *key, const char *v);
+long long lv_settings_get_int(lv_filter *f, const char *key);
+double lv_settings_get_double(lv_filter *f, const char *key);
+int lv_settings_get_bool(lv_filter *f, const char *key);
+/* apply_whisper_params_from_settings (whisper-params.cpp:102-144) followed by the language override of
+   transcription_filter_update (transcription-filter.cpp:415-450): key "whisper_language_select"
+   ("auto"/"" -> language "auto"... kept as given).  Rewrites the filter's whisper_full_params. */
+int lv_filter_apply_settings(lv_filter *f);
+
+/* stream shape + segmentation knobs (transcription-filter.cpp:476-541, transcription-filter-data.h:132-160) */
+int lv_filter_setup_audio(lv_filter *f, uint32_t sample_rate, uint32_t channels);
+void lv_filter_set_vad_mode(lv_filter *f, int vad_mode);
+void lv_filter_set_partial(lv_filter *f, int partial_transcription, int partial_latency_ms);
+void lv_filter_set_segment_duration(lv_filter *f, int segment_duration_ms);
+void lv_filter_set_max_sub_duration(lv_filter *f, int max_sub_duration_ms);
+void lv_filter_enable_audio_chunks_callback(lv_filter *f, int enable);
+/* parameters of the energy gate that stands in for Silero (initialize_vad, vad-processing.cpp:456-475) */
+void lv_filter_set_vad_gate(lv_filter *f, float gate_db, float slope_db, float threshold);
+
+/* callbacks; `user` is passed back.  Strings and arrays are valid only during the call.
+   on_text     <- set_text_callback (transcription-filter-callbacks.cpp:272-433): result after the English trim
+   on_chunk    <- audio_chunk_callback (transcription-filter-data.h:266-269)
+   on_request  <- fired at the top of run_inference_and_callbacks (whisper-processing.cpp:326-348) with the
+                  padded PCM about to be transcribed: how a harness observes the segmentation itself */
+typedef void (*lv_text_cb)(void *user, const lv_detection *result);
+typedef void (*lv_chunk_cb)(void *user, const float *pcm32f, size_t frames, int vad_state, const lv_detection *result);
+typedef void (*lv_request_cb)(void *user, const float *pcm32f, size_t n, uint64_t t0, uint64_t t1, int vad_state);
+void lv_filter_set_callbacks(lv_filter *f, lv_text_cb on_text, lv_chunk_cb on_chunk, lv_request_cb on_request, void *user);
+
+/* transcription_filter_filter_audio (transcription-filter.cpp:60-119): planar channel pointers, stamped
+   with the wall clock; dropped while inactive or without a model.  Returns 1 if buffered, 0 if dropped. */
+int lv_filter_filter_audio(lv_filter *f, const float *const *data, uint32_t frames);
+/* the offline harness's push (localvocal-offline-test.cpp:527-560): explicit timestamp, no model needed;
+   data == NULL pushes silence */
+int lv_filter_push_packet(lv_filter *f, const float *const *data, uint32_t frames, uint64_t timestamp_offset_ns);
+void lv_filter_clear_buffers(lv_filter *f); /* sets gf->clear_buffers (transcription-filter-callbacks.cpp:690-710) */
+size_t lv_filter_input_bytes(lv_filter *f);   /* input_buffers[0].size */
+size_t lv_filter_whisper_bytes(lv_filter *f); /* whisper_buffer.size */
+
+/* One pass of the segmentation the worker would run for the current vad_mode
+   (vad_based_segmentation / hybrid_vad_segmentation / vad_disabled_segmentation, vad-processing.cpp:125-454)
+   on the calling thread, with the vad_state carried inside the filter.  Works without a model (every
+   inference then returns DETECTION_RESULT_UNKNOWN).  state_out, if not NULL, receives
+   {vad_on, start_ts_offest_ms, end_ts_offset_ms, last_partial_segment_end_ts}. */
+int lv_filter_segmentation_step(lv_filter *f, uint64_t state_out[4]);
+void lv_filter_reset_vad_state(lv_filter *f);
+
+/* start_whisper_thread_with_path / shutdown_whisper_thread (whisper-utils.cpp:9-51): model + worker
+   thread running whisper_loop (whisper-processing.cpp:361-431).  0 on success. */
+int lv_filter_start(lv_filter *f, const char *model_path);
+void lv_filter_stop(lv_filter *f);
+
+/* VadIterator::process + get_speech_timestamps (silero-vad-onnx.cpp:262-309) on a standalone iterator
+   with the filter's gate: writes up to cap (start,end) sample pairs, returns the count. */
+int lv_vad_speech_timestamps(lv_filter *f, const float *pcm, size_t n, int reset_state, int *pairs, int cap);
+/* remove_leading_trailing_nonalpha (transcription-utils.cpp:91-129) */
+void lv_remove_leading_trailing_nonalpha(const char *in, char *out, size_t n);
+/* stream_resampler: feeds one packet, returns the number of 16 kHz samples written (<= cap) */
+int lv_resample(lv_filter *f, const float *const *data, uint32_t frames, float *out, int cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -108,7 +108,21 @@ EXPORTED_SYMBOLS = [
     "lv_filter_create", "lv_filter_destroy", "lv_filter_params", "lv_filter_set_language", "lv_filter_set_thresholds",
     "lv_filter_set_context_sentences", "lv_filter_push_sentence", "lv_filter_set_gpu_device", "lv_filter_load_model",
     "lv_filter_unload_model", "lv_filter_context", "lv_run_whisper_inference", "lv_to_timestamp",
+    "lv_settings_set_int", "lv_settings_set_double", "lv_settings_set_bool", "lv_settings_set_string",
+    "lv_settings_get_int", "lv_settings_get_double", "lv_settings_get_bool", "lv_filter_apply_settings",
+    "lv_filter_setup_audio", "lv_filter_set_vad_mode", "lv_filter_set_partial", "lv_filter_set_segment_duration",
+    "lv_filter_set_max_sub_duration", "lv_filter_enable_audio_chunks_callback", "lv_filter_set_vad_gate",
+    "lv_filter_set_callbacks", "lv_filter_filter_audio", "lv_filter_push_packet", "lv_filter_clear_buffers",
+    "lv_filter_input_bytes", "lv_filter_whisper_bytes", "lv_filter_segmentation_step", "lv_filter_reset_vad_state",
+    "lv_filter_start", "lv_filter_stop", "lv_vad_speech_timestamps", "lv_remove_leading_trailing_nonalpha",
+    "lv_resample",
 ]
+
+LV_TEXT_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(LvDetection))
+LV_CHUNK_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_float), C.c_size_t, C.c_int, C.POINTER(LvDetection))
+LV_REQUEST_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_float), C.c_size_t, C.c_uint64, C.c_uint64, C.c_int)
+VAD_MODE_ACTIVE, VAD_MODE_HYBRID, VAD_MODE_DISABLED = 0, 1, 2
+VAD_STATE_WAS_ON, VAD_STATE_WAS_OFF, VAD_STATE_IS_OFF, VAD_STATE_PARTIAL = 0, 1, 2, 3
 
 
 def build(force: bool = False) -> str:
@@ -210,6 +224,39 @@ def lib():
     L.lv_filter_context.argtypes = [P]
     L.lv_run_whisper_inference.argtypes = [P, FP, C.c_size_t, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(LvDetection)]
     L.lv_to_timestamp.argtypes = [C.c_uint64, C.c_char_p, C.c_size_t]
+    FPP = C.POINTER(C.POINTER(C.c_float))
+    L.lv_settings_set_int.argtypes = [P, C.c_char_p, C.c_longlong]
+    L.lv_settings_set_double.argtypes = [P, C.c_char_p, C.c_double]
+    L.lv_settings_set_bool.argtypes = [P, C.c_char_p, C.c_int]
+    L.lv_settings_set_string.argtypes = [P, C.c_char_p, C.c_char_p]
+    L.lv_settings_get_int.restype = C.c_longlong
+    L.lv_settings_get_int.argtypes = [P, C.c_char_p]
+    L.lv_settings_get_double.restype = C.c_double
+    L.lv_settings_get_double.argtypes = [P, C.c_char_p]
+    L.lv_settings_get_bool.argtypes = [P, C.c_char_p]
+    L.lv_filter_apply_settings.argtypes = [P]
+    L.lv_filter_setup_audio.argtypes = [P, C.c_uint32, C.c_uint32]
+    L.lv_filter_set_vad_mode.argtypes = [P, C.c_int]
+    L.lv_filter_set_partial.argtypes = [P, C.c_int, C.c_int]
+    L.lv_filter_set_segment_duration.argtypes = [P, C.c_int]
+    L.lv_filter_set_max_sub_duration.argtypes = [P, C.c_int]
+    L.lv_filter_enable_audio_chunks_callback.argtypes = [P, C.c_int]
+    L.lv_filter_set_vad_gate.argtypes = [P, C.c_float, C.c_float, C.c_float]
+    L.lv_filter_set_callbacks.argtypes = [P, LV_TEXT_CB, LV_CHUNK_CB, LV_REQUEST_CB, C.c_void_p]
+    L.lv_filter_filter_audio.argtypes = [P, FPP, C.c_uint32]
+    L.lv_filter_push_packet.argtypes = [P, FPP, C.c_uint32, C.c_uint64]
+    L.lv_filter_clear_buffers.argtypes = [P]
+    L.lv_filter_input_bytes.restype = C.c_size_t
+    L.lv_filter_input_bytes.argtypes = [P]
+    L.lv_filter_whisper_bytes.restype = C.c_size_t
+    L.lv_filter_whisper_bytes.argtypes = [P]
+    L.lv_filter_segmentation_step.argtypes = [P, C.POINTER(C.c_uint64)]
+    L.lv_filter_reset_vad_state.argtypes = [P]
+    L.lv_filter_start.argtypes = [P, C.c_char_p]
+    L.lv_filter_stop.argtypes = [P]
+    L.lv_vad_speech_timestamps.argtypes = [P, FP, C.c_size_t, C.c_int, C.POINTER(C.c_int), C.c_int]
+    L.lv_remove_leading_trailing_nonalpha.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+    L.lv_resample.argtypes = [P, FPP, C.c_uint32, FP, C.c_int]
     _lib = L
     return L
 
@@ -402,3 +449,86 @@ class Filter:
         toks = [dict(id=out.tokens[i].id, p=out.tokens[i].p) for i in range(out.n_tokens)]
         return dict(result=out.result, text=out.text or b"", start=out.start_timestamp_ms, end=out.end_timestamp_ms,
                     tokens=toks, language=(out.language or b"").decode())
+
+    # ---- callers of the path: settings, audio tap, segmentation, worker (localvocal_hotpath.h, second half) ----
+    def set_setting(self, key: str, value):
+        k = key.encode()
+        if isinstance(value, bool):
+            self.L.lv_settings_set_bool(self.f, k, int(value))
+        elif isinstance(value, int):
+            self.L.lv_settings_set_int(self.f, k, value)
+        elif isinstance(value, float):
+            self.L.lv_settings_set_double(self.f, k, value)
+        else:
+            self.L.lv_settings_set_string(self.f, k, str(value).encode())
+
+    def apply_settings(self) -> int:
+        return self.L.lv_filter_apply_settings(self.f)
+
+    def setup_audio(self, sample_rate: int, channels: int) -> int:
+        self.channels = channels
+        return self.L.lv_filter_setup_audio(self.f, sample_rate, channels)
+
+    def set_callbacks(self, on_text=None, on_chunk=None, on_request=None):
+        """Python callables receiving plain dicts / numpy copies; kept alive on the instance."""
+        def det(d):
+            d = d.contents
+            return dict(result=d.result, text=(d.text or b""), start=d.start_timestamp_ms, end=d.end_timestamp_ms,
+                        n_tokens=d.n_tokens, language=(d.language or b"").decode())
+        self._cb_text = LV_TEXT_CB((lambda u, d: on_text(det(d))) if on_text else 0)
+        self._cb_chunk = LV_CHUNK_CB((lambda u, pcm, n, vs, d: on_chunk(np.ctypeslib.as_array(pcm, (n,)).copy(), vs, det(d)))
+                                     if on_chunk else 0)
+        self._cb_req = LV_REQUEST_CB((lambda u, pcm, n, t0, t1, vs: on_request(np.ctypeslib.as_array(pcm, (n,)).copy(), t0, t1, vs))
+                                     if on_request else 0)
+        self.L.lv_filter_set_callbacks(self.f, self._cb_text, self._cb_chunk, self._cb_req, None)
+
+    def _planar(self, data):
+        chans = [np.ascontiguousarray(c, dtype=np.float32) for c in data]
+        arr = (C.POINTER(C.c_float) * len(chans))(*[_fp(c) for c in chans])
+        return chans, arr
+
+    def push_packet(self, data, timestamp_offset_ns: int) -> int:
+        """data: list of per-channel float arrays, or an int frame count for silence."""
+        if isinstance(data, int):
+            return self.L.lv_filter_push_packet(self.f, None, data, timestamp_offset_ns)
+        chans, arr = self._planar(data)
+        return self.L.lv_filter_push_packet(self.f, arr, len(chans[0]), timestamp_offset_ns)
+
+    def filter_audio(self, data) -> int:
+        chans, arr = self._planar(data)
+        return self.L.lv_filter_filter_audio(self.f, arr, len(chans[0]))
+
+    def segmentation_step(self):
+        st = (C.c_uint64 * 4)()
+        rc = self.L.lv_filter_segmentation_step(self.f, st)
+        if rc != 0:
+            raise RuntimeError(f"lv_filter_segmentation_step failed: {rc}")
+        return dict(vad_on=bool(st[0]), start=st[1], end=st[2], last_partial_end=st[3])
+
+    def vad_speech_timestamps(self, pcm, reset_state=True, cap=256):
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        pairs = (C.c_int * (2 * cap))()
+        n = self.L.lv_vad_speech_timestamps(self.f, _fp(pcm), len(pcm), int(reset_state), pairs, cap)
+        if n < 0:
+            raise RuntimeError("lv_vad_speech_timestamps failed")
+        return [(pairs[2 * i], pairs[2 * i + 1]) for i in range(min(n, cap))]
+
+    def resample(self, data):
+        chans, arr = self._planar(data)
+        out = np.zeros(len(chans[0]) * 2 + 64, dtype=np.float32)
+        n = self.L.lv_resample(self.f, arr, len(chans[0]), _fp(out), len(out))
+        if n < 0:
+            raise RuntimeError("lv_resample failed")
+        return out[:n].copy()
+
+    def start(self, model_path: str) -> int:
+        return self.L.lv_filter_start(self.f, model_path.encode())
+
+    def stop(self):
+        self.L.lv_filter_stop(self.f)
+
+
+def remove_leading_trailing_nonalpha(s: bytes) -> bytes:
+    buf = C.create_string_buffer(len(s) + 8)
+    lib().lv_remove_leading_trailing_nonalpha(s, buf, len(buf))
+    return buf.value

@@ -43,6 +43,20 @@ transcription_filter_data::transcription_filter_data() {
     whisper_params.suppress_non_speech_tokens = false;
     language_storage = "en";
     whisper_params.language = language_storage.c_str();
+    input_cv.emplace();
+    last_sub_render_time = now_ms();
+    // 16 kHz mono until the host says otherwise (transcription_filter_setup_audio)
+    frames = (size_t)(16000.0f / (1000.0f / 11000));
+    copy_buffers[0].assign(frames, 0.0f);
+    resampler_to_whisper.reset(new stream_resampler(16000, 1));
+}
+
+transcription_filter_data::~transcription_filter_data() {
+    // a worker still running would touch freed members: stop it first (transcription-filter.cpp:143-170)
+    try {
+        shutdown_whisper_thread(this);
+    } catch (...) {
+    }
 }
 
 struct whisper_context *init_whisper_context(const std::string &model_path_in, struct transcription_filter_data *gf) {
@@ -186,21 +200,279 @@ std::string to_timestamp(uint64_t t_ms_offset) {
 struct lv_filter {
     transcription_filter_data gf;
     DetectionResultWithText last;
+    lv_settings settings;
+    vad_state vs = {false, 0, 0, 0};
+    float gate_db = -40.0f, slope_db = 3.0f, vad_threshold = 0.5f;
+    lv_text_cb on_text = nullptr;
+    lv_chunk_cb on_chunk = nullptr;
+    lv_request_cb on_request = nullptr;
+    void *user = nullptr;
 };
+
+namespace {
+
+lv_detection flatten(const DetectionResultWithText &r) {
+    lv_detection d;
+    d.result = (int)r.result;
+    d.text = r.text.c_str();
+    d.start_timestamp_ms = r.start_timestamp_ms;
+    d.end_timestamp_ms = r.end_timestamp_ms;
+    d.tokens = r.tokens.data();
+    d.n_tokens = (int)r.tokens.size();
+    d.language = r.language.c_str();
+    return d;
+}
+
+void make_vad(lv_filter *f) {
+    f->gf.vad.reset(new VadIterator(VadIterator::energy_gate(f->gate_db, f->slope_db), WHISPER_SAMPLE_RATE, 32, f->vad_threshold,
+                                    100, 100, 100));
+}
+
+// every entry below returns an error code instead of letting an exception cross the C boundary
+template <typename F> int lv_guard(F &&fn) {
+    try {
+        return fn();
+    } catch (const std::exception &e) {
+        mw::log_msg(kLogError, "localvocal: %s\n", e.what());
+        return -100;
+    } catch (...) {
+        return -101;
+    }
+}
+
+}  // namespace
 
 extern "C" {
 
 lv_filter *lv_filter_create(void) {
     try {
-        return new lv_filter();
+        lv_filter *f = new lv_filter();
+        apply_whisper_params_defaults_on_settings(&f->settings);
+        // transcription-filter-properties.cpp:680-750 defaults for the keys read outside whisper-params.cpp
+        f->settings.def_strings["whisper_language_select"] = "en";
+        f->settings.def_ints["n_context_sentences"] = 0;
+        f->settings.def_doubles["sentence_psum_accept_thresh"] = 0.4;
+        f->settings.def_doubles["vad_threshold"] = 0.65;
+        make_vad(f);
+        return f;
     } catch (...) {
         return nullptr;
     }
 }
 void lv_filter_destroy(lv_filter *f) {
     if (!f) return;
-    shutdown_whisper_context(&f->gf);
+    try {
+        shutdown_whisper_thread(&f->gf);
+    } catch (...) {
+    }
     delete f;
+}
+
+int lv_settings_set_int(lv_filter *f, const char *key, long long v) {
+    if (!f || !key) return -1;
+    f->settings.ints[key] = v;
+    return 0;
+}
+int lv_settings_set_double(lv_filter *f, const char *key, double v) {
+    if (!f || !key) return -1;
+    f->settings.doubles[key] = v;
+    return 0;
+}
+int lv_settings_set_bool(lv_filter *f, const char *key, int v) {
+    if (!f || !key) return -1;
+    f->settings.bools[key] = v != 0;
+    return 0;
+}
+int lv_settings_set_string(lv_filter *f, const char *key, const char *v) {
+    if (!f || !key || !v) return -1;
+    f->settings.strings[key] = v;
+    return 0;
+}
+long long lv_settings_get_int(lv_filter *f, const char *key) { return f && key ? f->settings.get_int(key) : 0; }
+double lv_settings_get_double(lv_filter *f, const char *key) { return f && key ? f->settings.get_double(key) : 0.0; }
+int lv_settings_get_bool(lv_filter *f, const char *key) { return f && key ? (int)f->settings.get_bool(key) : 0; }
+
+int lv_filter_apply_settings(lv_filter *f) {
+    if (!f) return -1;
+    return lv_guard([&] {
+        transcription_filter_data &gf = f->gf;
+        std::lock_guard<std::mutex> lock(gf.whisper_ctx_mutex);
+        gf.n_context_sentences = (int)f->settings.get_int("n_context_sentences");
+        gf.sentence_psum_accept_thresh = (float)f->settings.get_double("sentence_psum_accept_thresh");
+        apply_whisper_params_from_settings(gf.whisper_params, &f->settings);
+        const char *sel = f->settings.get_string("whisper_language_select");
+        const bool language_selected = sel != nullptr && sel[0] != 0;
+        gf.language_storage = language_selected ? sel : "auto";
+        gf.whisper_params.language = gf.language_storage.c_str();
+        gf.whisper_params.detect_language = !language_selected;
+        f->vad_threshold = (float)f->settings.get_double("vad_threshold");
+        if (gf.vad) gf.vad->set_threshold(f->vad_threshold);
+        return 0;
+    });
+}
+
+int lv_filter_setup_audio(lv_filter *f, uint32_t sample_rate, uint32_t channels) {
+    if (!f) return -1;
+    return lv_guard([&] {
+        transcription_filter_setup_audio(&f->gf, sample_rate, channels);
+        f->vs = {false, 0, 0, 0};
+        return 0;
+    });
+}
+void lv_filter_set_vad_mode(lv_filter *f, int vad_mode) {
+    if (f) f->gf.vad_mode = vad_mode;
+}
+void lv_filter_set_partial(lv_filter *f, int partial_transcription, int partial_latency_ms) {
+    if (!f) return;
+    f->gf.partial_transcription = partial_transcription != 0;
+    f->gf.partial_latency = partial_latency_ms;
+}
+void lv_filter_set_segment_duration(lv_filter *f, int ms) {
+    if (f) f->gf.segment_duration = ms;
+}
+void lv_filter_set_max_sub_duration(lv_filter *f, int ms) {
+    if (f) f->gf.max_sub_duration = (size_t)std::max(ms, 0);
+}
+void lv_filter_enable_audio_chunks_callback(lv_filter *f, int enable) {
+    if (f) f->gf.enable_audio_chunks_callback = enable != 0;
+}
+void lv_filter_set_vad_gate(lv_filter *f, float gate_db, float slope_db, float threshold) {
+    if (!f) return;
+    f->gate_db = gate_db;
+    f->slope_db = slope_db > 0.0f ? slope_db : 3.0f;
+    f->vad_threshold = threshold;
+    try {
+        make_vad(f);
+    } catch (...) {
+    }
+}
+
+void lv_filter_set_callbacks(lv_filter *f, lv_text_cb on_text, lv_chunk_cb on_chunk, lv_request_cb on_request, void *user) {
+    if (!f) return;
+    f->on_text = on_text;
+    f->on_chunk = on_chunk;
+    f->on_request = on_request;
+    f->user = user;
+    f->gf.setTextCallback = nullptr;
+    f->gf.audioChunkCallback = nullptr;
+    f->gf.inferenceRequestObserver = nullptr;
+    if (on_text)
+        f->gf.setTextCallback = [f](const DetectionResultWithText &r) {
+            const lv_detection d = flatten(r);
+            f->on_text(f->user, &d);
+        };
+    if (on_chunk)
+        f->gf.audioChunkCallback = [f](const float *pcm, size_t frames, int vad_state, const DetectionResultWithText &r) {
+            const lv_detection d = flatten(r);
+            f->on_chunk(f->user, pcm, frames, vad_state, &d);
+        };
+    if (on_request)
+        f->gf.inferenceRequestObserver = [f](const float *pcm, size_t n, uint64_t t0, uint64_t t1, int vad_state) {
+            f->on_request(f->user, pcm, n, t0, t1, vad_state);
+        };
+}
+
+int lv_filter_filter_audio(lv_filter *f, const float *const *data, uint32_t frames) {
+    if (!f || !data || frames == 0) return 0;
+    return lv_guard([&] {
+        if (!f->gf.active || f->gf.whisper_context == nullptr) return 0;
+        transcription_filter_filter_audio(&f->gf, data, frames);
+        return 1;
+    });
+}
+int lv_filter_push_packet(lv_filter *f, const float *const *data, uint32_t frames, uint64_t timestamp_offset_ns) {
+    if (!f || frames == 0) return -1;
+    return lv_guard([&] {
+        transcription_filter_push_packet(&f->gf, data, frames, timestamp_offset_ns);
+        return 0;
+    });
+}
+void lv_filter_clear_buffers(lv_filter *f) {
+    if (f) f->gf.clear_buffers = true;
+}
+size_t lv_filter_input_bytes(lv_filter *f) {
+    if (!f) return 0;
+    std::lock_guard<std::mutex> lock(f->gf.whisper_buf_mutex);
+    return f->gf.input_buffers[0].size;
+}
+size_t lv_filter_whisper_bytes(lv_filter *f) { return f ? f->gf.whisper_buffer.size : 0; }
+
+int lv_filter_segmentation_step(lv_filter *f, uint64_t state_out[4]) {
+    if (!f) return -1;
+    return lv_guard([&] {
+        transcription_filter_data *gf = &f->gf;
+        if (gf->clear_buffers) {
+            gf->resampled_buffer.clear();
+            gf->whisper_buffer.clear();
+            f->vs = {false, now_ms(), 0, 0};
+            gf->clear_buffers = false;
+        }
+        if (gf->vad_mode == VAD_MODE_HYBRID) f->vs = hybrid_vad_segmentation(gf, f->vs);
+        else if (gf->vad_mode == VAD_MODE_ACTIVE) f->vs = vad_based_segmentation(gf, f->vs);
+        else if (gf->vad_mode == VAD_MODE_DISABLED) f->vs = vad_disabled_segmentation(gf, f->vs);
+        else return -2;
+        if (state_out) {
+            state_out[0] = f->vs.vad_on;
+            state_out[1] = f->vs.start_ts_offest_ms;
+            state_out[2] = f->vs.end_ts_offset_ms;
+            state_out[3] = f->vs.last_partial_segment_end_ts;
+        }
+        return 0;
+    });
+}
+void lv_filter_reset_vad_state(lv_filter *f) {
+    if (f) f->vs = {false, 0, 0, 0};
+}
+
+int lv_filter_start(lv_filter *f, const char *model_path) {
+    if (!f || !model_path) return -1;
+    return lv_guard([&] {
+        if (f->gf.whisper_context != nullptr) return -2;
+        start_whisper_thread_with_path(&f->gf, model_path, "silero-vad/silero_vad.onnx");
+        if (f->gf.whisper_context == nullptr) return -3;
+        make_vad(f);  // keep the gate configured through lv_filter_set_vad_gate
+        return 0;
+    });
+}
+void lv_filter_stop(lv_filter *f) {
+    if (!f) return;
+    try {
+        shutdown_whisper_thread(&f->gf);
+    } catch (...) {
+    }
+}
+
+int lv_vad_speech_timestamps(lv_filter *f, const float *pcm, size_t n, int reset_state, int *pairs, int cap) {
+    if (!f || (!pcm && n) || (!pairs && cap > 0)) return -1;
+    return lv_guard([&] {
+        if (!f->gf.vad) make_vad(f);
+        std::vector<float> wav(pcm, pcm + n);
+        f->gf.vad->process(wav, reset_state != 0);
+        const std::vector<timestamp_t> st = f->gf.vad->get_speech_timestamps();
+        for (int i = 0; i < (int)st.size() && i < cap; ++i) {
+            pairs[2 * i] = st[i].start;
+            pairs[2 * i + 1] = st[i].end;
+        }
+        return (int)st.size();
+    });
+}
+void lv_remove_leading_trailing_nonalpha(const char *in, char *out, size_t n) {
+    if (!in || !out || n == 0) return;
+    try {
+        snprintf(out, n, "%s", remove_leading_trailing_nonalpha(in).c_str());
+    } catch (...) {
+        out[0] = 0;
+    }
+}
+int lv_resample(lv_filter *f, const float *const *data, uint32_t frames, float *out, int cap) {
+    if (!f || !data || !out) return -1;
+    return lv_guard([&] {
+        std::vector<float> o;
+        f->gf.resampler_to_whisper->resample(data, frames, o);
+        if ((int)o.size() > cap) return -2;
+        memcpy(out, o.data(), o.size() * sizeof(float));
+        return (int)o.size();
+    });
 }
 struct whisper_full_params *lv_filter_params(lv_filter *f) { return f ? &f->gf.whisper_params : nullptr; }
 void lv_filter_set_language(lv_filter *f, const char *language) {
@@ -250,7 +522,11 @@ int lv_filter_load_model(lv_filter *f, const char *model_path) {
     }
 }
 void lv_filter_unload_model(lv_filter *f) {
-    if (f) shutdown_whisper_context(&f->gf);
+    if (!f) return;
+    try {
+        shutdown_whisper_thread(&f->gf);  // context half + joins a worker if one was started
+    } catch (...) {
+    }
 }
 struct whisper_context *lv_filter_context(lv_filter *f) { return f ? f->gf.whisper_context : nullptr; }
 
