@@ -444,6 +444,7 @@ int mw_decode(struct whisper_context *ctx, const whisper_token *tokens, int n, i
         MW_HIP(hipStreamSynchronize(c.st));
         decode(c, tokens, pos.data(), slot.data(), n, rows.data(), (int)rows.size());
         MW_HIP(hipStreamSynchronize(c.st));
+        check_mega(c);
         return 0;
     });
 }

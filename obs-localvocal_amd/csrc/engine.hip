@@ -33,11 +33,25 @@ const char *const k_non_speech[] = {
 
 Context::~Context() {
     (void)hipSetDevice(device);
+    if (d_mega_prof && !mega_prof_path.empty()) {  // developer aid: dump the last launch's phase stamps
+        const size_t n = (size_t)model.hp.n_text_layer * mega_grid * MEGA_PROF_STRIDE;
+        std::vector<unsigned long long> h(n);
+        if (hipDeviceSynchronize() == hipSuccess && hipMemcpy(h.data(), d_mega_prof, n * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            if (FILE *f = fopen(mega_prof_path.c_str(), "w")) {
+                fprintf(f, "%d %d %d\n", model.hp.n_text_layer, mega_grid, MEGA_PROF_STRIDE);
+                for (size_t i = 0; i < n; ++i) fprintf(f, "%llu%c", h[i], (i % MEGA_PROF_STRIDE == MEGA_PROF_STRIDE - 1) ? '\n' : ' ');
+                fclose(f);
+            }
+        }
+        (void)hipFree(d_mega_prof);
+    }
     void *ptrs[] = {d_pcm, d_mel_raw, d_mel, d_gmax, d_conv_in, d_x1, d_h, d_qk, d_vt, d_p, d_att, d_ff, d_enc_out, d_x,
                     d_s, d_cross, d_kself, d_vself, d_kv_idx[0], d_kv_idx[1], d_tokens, d_pos, d_slot, d_rows, d_xd, d_q,
-                    d_attd, d_ffd, d_part, d_logits, d_work, d_suppress, d_row_state, d_row_res};
+                    d_attd, d_ffd, d_part, d_logits, d_work, d_suppress, d_row_state, d_row_res,
+                    d_mega_layers, d_mega_act, d_mega_sync, d_xout, d_head_cnt};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    if (h_mega_abort) (void)hipHostFree(h_mega_abort);
     if (h_ints) (void)hipHostFree(h_ints);
     if (h_row_state) (void)hipHostFree(h_row_state);
     if (h_row_res) (void)hipHostFree(h_row_res);
@@ -110,6 +124,56 @@ std::unique_ptr<Context> create_context(const unsigned char *data, size_t size, 
     // the matrix-core projection variant measured ~5 % slower per window than the VALU one at 5 rows
     // (profiles/r01_*): kept selectable for wider batches
     c->mfma_proj = wt == DType::BF16 && getenv("MI355_WHISPER_MFMA_PROJ") != nullptr;
+    // persistent decode kernel: the whole decoder stack of a <= 5-row step in one cooperative launch
+    if (wt == DType::BF16 && TC <= (size_t)MEGA_TC_MAX && hp.n_text_state == hp.n_text_head * 64 && !getenv("MI355_WHISPER_NO_WG_ATTN")) {
+        dev_alloc(c->d_head_cnt, 64);
+        MW_HIP(hipMemsetAsync(c->d_head_cnt, 0, 64 * sizeof(unsigned), c->st));
+        c->wg_attn = true;
+    }
+    // Measured slower than the graph-replayed step (cross-XCD hand-offs cost as much as a launch), so the
+    // persistent kernel is an opt-in experiment: MI355_WHISPER_MEGA=1
+    if (wt == DType::BF16 && !c->mfma_proj && getenv("MI355_WHISPER_MEGA")) {
+        std::string why;
+        const int grid = mega_max_grid(device);
+        const int dd = hp.n_text_state, HH = hp.n_text_head;
+        if (grid > 0 && mega_supported(dd, HH, (int)TC, (int)L, grid, &why)) {
+            const MegaActLayout lay = mega_act_layout(dd, HH);
+            c->mega_grid = grid;
+            c->mega_act_stride = lay.total;
+            dev_alloc(c->d_mega_act, lay.total * L);
+            dev_alloc(c->d_mega_sync, mega_sync_bytes() / sizeof(unsigned));
+            MW_HIP(hipMemsetAsync(c->d_mega_sync, 0, mega_sync_bytes(), c->st));
+            dev_alloc(c->d_xout, (size_t)8 * dd);
+            MW_HIP(hipHostMalloc((void **)&c->h_mega_abort, 64));
+            *c->h_mega_abort = 0;
+            std::vector<MegaLayerW> lw(L);
+            const size_t kv_layer = (size_t)KV_SLOTS * TC * dd * ws;
+            for (size_t l = 0; l < L; ++l) {
+                const DecLayer &e = c->model.dec[l];
+                MegaLayerW &w = lw[l];
+                w.qkv_w = (const bf16_t *)e.qkv_w; w.out_w = (const bf16_t *)e.out_w; w.cq_w = (const bf16_t *)e.cq_w;
+                w.co_w = (const bf16_t *)e.co_w; w.fc1_w = (const bf16_t *)e.fc1_w; w.fc2_w = (const bf16_t *)e.fc2_w;
+                w.qkv_b = e.qkv_b; w.out_b = e.out_b; w.cq_b = e.cq_b; w.co_b = e.co_b; w.fc1_b = e.fc1_b; w.fc2_b = e.fc2_b;
+                w.ln1_w = e.ln1_w; w.ln1_b = e.ln1_b; w.lnc_w = e.lnc_w; w.lnc_b = e.lnc_b; w.ln2_w = e.ln2_w; w.ln2_b = e.ln2_b;
+                const char *ck = (const char *)c->d_cross + l * 2 * T * dd * ws;
+                w.ck = (const bf16_t *)ck;
+                w.cv = (const bf16_t *)(ck + T * dd * ws);
+                w.ks = (bf16_t *)((char *)c->d_kself + l * kv_layer);
+                w.vs = (bf16_t *)((char *)c->d_vself + l * kv_layer);
+            }
+            dev_alloc(c->d_mega_layers, L);
+            MW_HIP(hipMemcpyAsync(c->d_mega_layers, lw.data(), L * sizeof(MegaLayerW), hipMemcpyHostToDevice, c->st));
+            MW_HIP(hipStreamSynchronize(c->st));  // lw is a stack-lifetime host buffer
+            c->use_mega = true;
+            if (const char *pp = getenv("MI355_WHISPER_MEGA_PROF")) {
+                c->mega_prof_path = pp;
+                dev_alloc(c->d_mega_prof, L * (size_t)grid * MEGA_PROF_STRIDE);
+                MW_HIP(hipMemsetAsync(c->d_mega_prof, 0, L * (size_t)grid * MEGA_PROF_STRIDE * 8, c->st));
+            }
+        } else {
+            log_msg(LOG_INFO, "mi355_whisper: persistent decode kernel not used (%s)\n", grid > 0 ? why.c_str() : "does not fit a CU");
+        }
+    }
     MW_HIP(hipStreamSynchronize(c->st));
     log_msg(LOG_INFO, "mi355_whisper: model loaded (%zu params, %s weights, %.1f MB arena) on device %d (%s)\n",
             c->model.n_params, wt == DType::F32 ? "fp32" : "bf16", c->model.arena_used / 1048576.0, device,
@@ -271,6 +335,18 @@ void kv_reorder(Context &c, const int *src, int n_past) {
     c.kv_cur ^= 1;
 }
 
+void check_mega(Context &c) {
+    if (!c.mega_launched || !c.h_mega_abort || *c.h_mega_abort == 0) return;
+    // a workgroup gave up waiting at a grid barrier: the step's results are invalid.  Reset the sync area
+    // and stop using the persistent kernel on this context.
+    *c.h_mega_abort = 0;
+    c.use_mega = false;
+    c.mega_epoch = 0;
+    MW_HIP(hipMemsetAsync(c.d_mega_sync, 0, mega_sync_bytes(), c.st));
+    MW_HIP(hipStreamSynchronize(c.st));
+    throw std::runtime_error("persistent decode kernel timed out at a grid barrier (results discarded; later steps use per-kernel launches)");
+}
+
 void decode(Context &c, const int *tokens, const int *pos, const int *slot, int n, const int *logit_rows,
             int n_logit_rows) {
     const Model &m = c.model;
@@ -292,6 +368,7 @@ void decode(Context &c, const int *tokens, const int *pos, const int *slot, int 
     const double t0 = now_ms();
     // the pinned staging block may still be read by the previous call's copies
     MW_HIP(hipStreamSynchronize(st));
+    check_mega(c);
     int *hi = c.h_ints;
     memcpy(hi, tokens, n * sizeof(int));
     memcpy(hi + TC, pos, n * sizeof(int));
@@ -319,6 +396,8 @@ void decode(Context &c, const int *tokens, const int *pos, const int *slot, int 
         const float qk_scale = powf(64.0f, -0.25f);
         const int splits = std::min(CROSS_SPLITS_MAX, std::max(ceil_div(n_ctx, 256), ceil_div(n_ctx, 128)));
         const size_t kv_layer = (size_t)KV_SLOTS * TC * d * ws;
+        // <= 5 rows on bf16 K/V: workgroup-wide attention kernels (mega.hip), cross-attention combines in-kernel
+        const bool wg_attn = c.wg_attn && n <= 5 && ceil_div(n_ctx, splits) <= MEGA_CROSS_PER_MAX;
         for (int l = 0; l < hp.n_text_layer; ++l) {
             const DecLayer &e = m.dec[l];
             {
@@ -329,8 +408,12 @@ void decode(Context &c, const int *tokens, const int *pos, const int *slot, int 
                 g.kv_t = wt; g.d_slot = c.d_slot; g.d_pos = c.d_pos; g.n_text_ctx = TC; g.tag = GEMV_QKV;
                 gemv(g);
             }
-            launch_self_attn(c.d_q, (char *)c.d_kself + l * kv_layer, (char *)c.d_vself + l * kv_layer, wt, c.d_slot, c.d_pos,
-                             c.d_kv_idx[c.kv_cur], c.d_attd, act_t, n, H, d, TC, st);
+            if (wg_attn)
+                launch_self_attn_wg(c.d_q, (char *)c.d_kself + l * kv_layer, (char *)c.d_vself + l * kv_layer, c.d_slot, c.d_pos,
+                                    c.d_kv_idx[c.kv_cur], c.d_attd, act_t, n, H, d, TC, st);
+            else
+                launch_self_attn(c.d_q, (char *)c.d_kself + l * kv_layer, (char *)c.d_vself + l * kv_layer, wt, c.d_slot, c.d_pos,
+                                 c.d_kv_idx[c.kv_cur], c.d_attd, act_t, n, H, d, TC, st);
             {
                 GemvArgs g;
                 g.x = (const float *)c.d_attd; g.x_bf16 = mf; g.ldx = d; g.n = n; g.W = e.out_w; g.bias = e.out_b; g.N = d; g.K = d;
@@ -344,8 +427,12 @@ void decode(Context &c, const int *tokens, const int *pos, const int *slot, int 
                 gemv(g);
             }
             const char *ck = (const char *)c.d_cross + (size_t)l * 2 * hp.n_audio_ctx * d * ws;
-            launch_cross_attn(c.d_q, ck, ck + (size_t)hp.n_audio_ctx * d * ws, wt, c.d_part, c.d_attd, act_t, n, H, d, n_ctx,
-                              splits, st);
+            if (wg_attn)
+                launch_cross_attn_wg(c.d_q, ck, ck + (size_t)hp.n_audio_ctx * d * ws, c.d_part, c.d_attd, act_t, c.d_head_cnt, n, H, d,
+                                     n_ctx, splits, st);
+            else
+                launch_cross_attn(c.d_q, ck, ck + (size_t)hp.n_audio_ctx * d * ws, wt, c.d_part, c.d_attd, act_t, n, H, d, n_ctx,
+                                  splits, st);
             {
                 GemvArgs g;
                 g.x = (const float *)c.d_attd; g.x_bf16 = mf; g.ldx = d; g.n = n; g.W = e.co_w; g.bias = e.co_b; g.N = d; g.K = d;
@@ -374,7 +461,40 @@ void decode(Context &c, const int *tokens, const int *pos, const int *slot, int 
         }
     };
     const bool use_graph = c.use_graphs && c.prof_tag < 0;
-    if (!use_graph) {
+    if (c.use_mega && n <= 5 && c.prof_tag < 0) {
+        // persistent path: embed, ONE cooperative kernel for all layers, then the logits projection
+        MW_HIP(hipMemcpyAsync(c.d_tokens, hi, n * sizeof(int), hipMemcpyHostToDevice, st));
+        MW_HIP(hipMemcpyAsync(c.d_pos, hi + TC, n * sizeof(int), hipMemcpyHostToDevice, st));
+        MW_HIP(hipMemcpyAsync(c.d_slot, hi + 2 * TC, n * sizeof(int), hipMemcpyHostToDevice, st));
+        if (n_logit_rows)
+            MW_HIP(hipMemcpyAsync(c.d_rows, hi + 3 * TC, n_logit_rows * sizeof(int), hipMemcpyHostToDevice, st));
+        launch_embed(c.d_tokens, c.d_pos, m.tok_emb, wt, m.dec_pe, c.d_xd, n, d, st);
+        MegaArgs a;
+        a.layers = c.d_mega_layers;
+        a.n_layer = hp.n_text_layer; a.d = d; a.H = H; a.TC = TC; a.n = n; a.n_ctx = n_ctx;
+        a.splits = std::max(1, std::min(CROSS_SPLITS_MAX, c.mega_grid / H));
+        a.per = ceil_div(n_ctx, a.splits);
+        while (a.per > MEGA_CROSS_PER_MAX) {  // more keys than threads: cannot happen at n_audio_ctx 1500 with >= 3 splits
+            a.splits += 1;
+            MW_CHECK(a.splits <= CROSS_SPLITS_MAX, "decode: audio context too long for the persistent kernel");
+            a.per = ceil_div(n_ctx, a.splits);
+        }
+        a.x0 = c.d_xd; a.act = c.d_mega_act; a.act_layer_stride = c.mega_act_stride; a.x_out = c.d_xout;
+        a.slot = c.d_slot; a.pos = c.d_pos; a.kv_idx = c.d_kv_idx[c.kv_cur];
+        a.sync = c.d_mega_sync; a.epoch_base = c.mega_epoch; a.qk_scale = powf(64.0f, -0.25f);
+        a.prof = c.d_mega_prof;
+        launch_decode_mega(a, c.mega_grid, st);
+        c.mega_epoch += (unsigned)mega_barriers_per_launch(hp.n_text_layer);
+        c.mega_launched = true;
+        MW_HIP(hipMemcpyAsync(c.h_mega_abort, c.d_mega_sync + MEGA_SYNC_ABORT_WORD, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        if (n_logit_rows > 0) {
+            GemvArgs g;
+            g.x = c.d_xout; g.ldx = d; g.n = n_logit_rows; g.W = m.tok_emb; g.N = hp.n_vocab; g.K = d;
+            g.ln_w = m.dec_ln_w; g.ln_b = m.dec_ln_b; g.out = c.d_logits; g.ldo = hp.n_vocab; g.d_rows = c.d_rows;
+            g.tag = GEMV_LOGITS;
+            launch_gemv(g, wt, st);
+        }
+    } else if (!use_graph) {
         enqueue();
     } else {
         const uint64_t key = ((uint64_t)n << 40) | ((uint64_t)n_logit_rows << 24) | ((uint64_t)n_ctx << 4) | (uint64_t)c.kv_cur;
@@ -496,6 +616,7 @@ void process_and_sample(Context &c, const whisper_full_params &params, float t_c
                           nullptr, nullptr, c.st);
     MW_HIP(hipMemcpyAsync(c.h_row_res, c.d_row_res, n * sizeof(LogitsRowResult), hipMemcpyDeviceToHost, c.st));
     MW_HIP(hipStreamSynchronize(c.st));
+    check_mega(c);
     for (int r = 0; r < n; ++r) c.decoders[dec_idx[r]].sampled = c.h_row_res[r];
     c.tm.n_sample++;
     c.tm.sample_ms += now_ms() - t0;
