@@ -129,6 +129,7 @@ std::unique_ptr<Context> create_context(const unsigned char *data, size_t size, 
         dev_alloc(c->d_head_cnt, 64);
         MW_HIP(hipMemsetAsync(c->d_head_cnt, 0, 64 * sizeof(unsigned), c->st));
         c->wg_attn = true;
+        c->proj_wg = hp.n_text_state % 128 == 0 && hp.n_text_state <= 1280 && !c->mfma_proj && getenv("MI355_WHISPER_NO_PROJ_WG") == nullptr;
     }
     // Measured slower than the graph-replayed step (cross-XCD hand-offs cost as much as a launch), so the
     // persistent kernel is an opt-in experiment: MI355_WHISPER_MEGA=1
@@ -388,7 +389,11 @@ void decode(Context &c, const int *tokens, const int *pos, const int *slot, int 
         auto gemv = [&](const GemvArgs &g) {
             const bool prof = g.tag == c.prof_tag && c.prof_n + 2 <= (int)c.prof_ev.size();
             if (prof) MW_HIP(hipEventRecord(c.prof_ev[c.prof_n++], st));
-            if (mf) launch_gemv_mfma(g, st);  // matrix-core variant (dec_mfma.hip), opt-in
+            // LayerNorm-fused classes (qkv, cross-q, fc1) at <= 5 rows: one 16-feature tile per workgroup on the
+            // matrix cores, LayerNorm per wave (mega.hip); the residual classes stay on the VALU stream kernels,
+            // which spread their weight rows over 4x more workgroups (profiles/r01_*)
+            if (c.proj_wg && n <= 5 && g.ln_w && g.tag != GEMV_LOGITS) launch_proj_wg(g, st);
+            else if (mf && g.tag != GEMV_LOGITS) launch_gemv_mfma(g, st);  // matrix-core variant (dec_mfma.hip), opt-in
             else launch_gemv(g, wt, st);      // VALU weight-streaming path (dec.hip)
             if (prof) MW_HIP(hipEventRecord(c.prof_ev[c.prof_n++], st));
         };

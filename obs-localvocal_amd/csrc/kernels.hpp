@@ -192,6 +192,9 @@ void launch_self_attn_wg(const float *q, const void *kcache, const void *vcache,
                          const int *d_kv_idx, void *out, DType out_t, int n, int H, int d, int n_text_ctx, hipStream_t st);
 void launch_cross_attn_wg(const float *q, const void *kc, const void *vc, float *partial, void *out, DType out_t, unsigned *head_cnt,
                           int n, int H, int d, int n_ctx, int splits, hipStream_t st);
+// one decode projection on the matrix cores, workgroup = 16-feature tile (bf16 weights, <= 5 rows; direct classes
+// take bf16 rows, fc1 writes bf16 rows: the GemvArgs contract of launch_gemv_mfma)
+void launch_proj_wg(const GemvArgs &a, hipStream_t st);
 int mega_barriers_per_launch(int n_layer);
 size_t mega_sync_bytes();
 constexpr int MEGA_SYNC_ABORT_WORD = 32;

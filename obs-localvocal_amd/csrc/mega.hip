@@ -185,7 +185,7 @@ template <int TPB, int J> __device__ __forceinline__ void load_weights(WRegs<TPB
     }
 }
 
-enum { EPI_QKV = 0, EPI_RES = 1, EPI_SCALE = 2, EPI_GELU_BF16 = 3 };
+enum { EPI_QKV = 0, EPI_RES = 1, EPI_SCALE = 2, EPI_GELU_BF16 = 3, EPI_GELU_F32 = 4 };
 
 struct Epi {
     // EPI_QKV
@@ -218,8 +218,8 @@ constexpr int LN_MAX_F4 = 5;  // float4 per lane of a LayerNorm row: K <= 1280
 // LDS (row stride K + 8 elements: conflict-free 16-byte reads), each wave multiplies its k-steps of the
 // workgroup's tile(s), the 8 partial tiles meet in LDS and one thread per (feature, row) finishes.
 // `wr` holds this phase's weights, issued at a grid barrier two or more phases ago.
-template <int NB, bool LN, int EPI, int TPB, int J>
-__device__ __forceinline__ void proj_phase(unsigned long long *stamp, const WRegs<TPB, J> &wr, const Proj &p, const void *xin,
+template <int NB, bool LN, int EPI, int TPB, int J, bool LOADW = false>
+__device__ __forceinline__ void proj_phase(unsigned long long *stamp, WRegs<TPB, J> &wr, const Proj &p, const void *xin,
                                            const float *ln_w, const float *ln_b, int n, const Epi &e, float *lds) {
     const TileGeo g = make_tiles(p);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -251,6 +251,7 @@ __device__ __forceinline__ void proj_phase(unsigned long long *stamp, const WReg
                 gw[i] = on ? *reinterpret_cast<const float4 *>(ln_w + 4 * c) : make_float4(0, 0, 0, 0);
                 gb[i] = on ? *reinterpret_cast<const float4 *>(ln_b + 4 * c) : make_float4(0, 0, 0, 0);
             }
+            if constexpr (LOADW) load_weights(wr, p);  // after the row loads: vector loads return in order
             float s = 0.0f;
 #pragma unroll
             for (int i = 0; i < LN_MAX_F4; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
@@ -276,6 +277,8 @@ __device__ __forceinline__ void proj_phase(unsigned long long *stamp, const WReg
                     *reinterpret_cast<uint2 *>(xs + wave * ldxs + 4 * c) = pk;
                 }
             }
+        } else {
+            if constexpr (LOADW) load_weights(wr, p);
         }
     } else {
         const int nu = K >> 3;  // 16-byte pieces per row
@@ -287,6 +290,7 @@ __device__ __forceinline__ void proj_phase(unsigned long long *stamp, const WReg
                 const int c = tid + MT * i;
                 if (r < n && c < nu) t[r][i] = *reinterpret_cast<const uint4 *>((const bf16_t *)xin + (long)r * K + 8 * c);
             }
+        if constexpr (LOADW) load_weights(wr, p);
 #pragma unroll
         for (int r = 0; r < NB; ++r)
 #pragma unroll
@@ -341,8 +345,10 @@ __device__ __forceinline__ void proj_phase(unsigned long long *stamp, const WReg
             st_agent(e.xout + (long)erow * p.N + n_e, v + res_e);
         } else if constexpr (EPI == EPI_SCALE) {
             st_agent(e.fout + (long)erow * p.N + n_e, v * e.scale);
-        } else {
+        } else if constexpr (EPI == EPI_GELU_BF16) {
             st_agent(e.hout + (long)erow * e.ldo + n_e, to_bf16(gelu_f(v)));
+        } else {
+            st_agent(e.fout + (long)erow * e.ldo + n_e, gelu_f(v));
         }
     }
     if (stamp && tid == 0) stamp[3] = wall_clock64();
@@ -753,7 +759,58 @@ __global__ __launch_bounds__(MEGA_THREADS) void cross_attn_wg_kernel(const float
     cross_attn_phase<NB, OT>(q, kc, vc, part, out, head_cnt, n, H, d, n_ctx, splits, per, lds);
 }
 
+// ---- one projection as a kernel of its own: workgroup = one 16-feature tile, 8 waves split K ----
+template <int NB, bool LN, int EPI, int J>
+__global__ __launch_bounds__(MEGA_THREADS) void proj_wg_kernel(Proj p, const void *xin, const float *ln_w, const float *ln_b, int n,
+                                                                Epi e) {
+    __shared__ __attribute__((aligned(16))) float lds[MEGA_XS_BYTES / 4 + 8 * 64 * 4];
+    WRegs<1, J> w;
+    proj_phase<NB, LN, EPI, 1, J, true>(nullptr, w, p, xin, ln_w, ln_b, n, e, lds);
+}
+
 }  // namespace
+
+void launch_proj_wg(const GemvArgs &a, hipStream_t st) {
+    MW_CHECK(a.x && a.W && a.out && a.n >= 1 && a.n <= 5, "proj_wg: 1..5 rows");
+    MW_CHECK(a.N % 16 == 0 && a.K % 32 == 0 && a.ldx == a.K && !a.d_rows, "proj_wg: shape");
+    MW_CHECK((size_t)a.n * (a.K + 8) * 2 <= MEGA_XS_BYTES, "proj_wg: rows exceed the LDS staging area");
+    const bool ln = a.ln_w != nullptr;
+    const int spw = ceil_div(a.K / 32, 8);
+    Proj p{(const bf16_t *)a.W, a.bias, a.N, a.K, 0};
+    Epi e{};
+    const dim3 grid(a.N / 16), block(MT);
+#define MW_PROJ(NBv, LNv, EPIv, Jv) \
+    hipLaunchKernelGGL((proj_wg_kernel<NBv, LNv, EPIv, Jv>), grid, block, 0, st, p, (const void *)a.x, a.ln_w, a.ln_b, a.n, e)
+#define MW_PROJ_NB(LNv, EPIv, Jv) \
+    do {                           \
+        if (a.n == 1) MW_PROJ(1, LNv, EPIv, Jv); \
+        else MW_PROJ(5, LNv, EPIv, Jv);          \
+    } while (0)
+    if (a.qkv) {
+        MW_CHECK(ln && a.ln_b && spw <= 5 && a.K <= 256 * LN_MAX_F4 && a.N == 3 * a.K && a.ldo == a.K && a.kv_t == DType::BF16,
+                 "proj_wg: qkv class");
+        e.q = a.out; e.kc = (bf16_t *)a.kcache; e.vc = (bf16_t *)a.vcache; e.slot = a.d_slot; e.pos = a.d_pos; e.TC = a.n_text_ctx;
+        e.d = a.K; e.qk_scale = a.qk_scale;
+        MW_PROJ_NB(true, EPI_QKV, 5);
+    } else if (ln && a.act == ACT_GELU) {
+        MW_CHECK(a.ln_b && spw <= 5 && a.K <= 256 * LN_MAX_F4 && !a.R, "proj_wg: fc1 class");
+        e.hout = (bf16_t *)a.out; e.fout = a.out; e.ldo = (int)a.ldo;
+        if (a.out_bf16) MW_PROJ_NB(true, EPI_GELU_BF16, 5);
+        else MW_PROJ_NB(true, EPI_GELU_F32, 5);
+    } else if (ln) {
+        MW_CHECK(a.ln_b && spw <= 5 && a.K <= 256 * LN_MAX_F4 && !a.R && a.ldo == a.N && a.act == ACT_NONE, "proj_wg: cross-q class");
+        e.fout = a.out; e.scale = a.out_scale;
+        MW_PROJ_NB(true, EPI_SCALE, 5);
+    } else {
+        MW_CHECK(a.x_bf16 && a.R && a.ldo == a.N && a.act == ACT_NONE && a.out_scale == 1.0f && spw <= 20, "proj_wg: residual class");
+        e.res = a.R; e.xout = a.out;
+        if (spw <= 5) MW_PROJ_NB(false, EPI_RES, 5);
+        else MW_PROJ_NB(false, EPI_RES, 20);
+    }
+#undef MW_PROJ_NB
+#undef MW_PROJ
+    MW_HIP(hipGetLastError());
+}
 
 void launch_self_attn_wg(const float *q, const void *kcache, const void *vcache, const int *d_slot, const int *d_pos,
                          const int *d_kv_idx, void *out, DType out_t, int n, int H, int d, int n_text_ctx, hipStream_t st) {
