@@ -399,7 +399,8 @@ void decode(Context &c, const int *tokens, const int *pos, const int *slot, int 
         };
         launch_embed(c.d_tokens, c.d_pos, m.tok_emb, wt, m.dec_pe, c.d_xd, n, d, st);
         const float qk_scale = powf(64.0f, -0.25f);
-        const int splits = std::min(CROSS_SPLITS_MAX, std::max(ceil_div(n_ctx, 256), ceil_div(n_ctx, 128)));
+        int splits = std::min(CROSS_SPLITS_MAX, std::max(ceil_div(n_ctx, 256), ceil_div(n_ctx, 128)));
+        if (const char *sv = getenv("MI355_WHISPER_CROSS_SPLITS")) splits = std::max(ceil_div(n_ctx, 256), std::min(CROSS_SPLITS_MAX, atoi(sv)));
         const size_t kv_layer = (size_t)KV_SLOTS * TC * d * ws;
         // <= 5 rows on bf16 K/V: workgroup-wide attention kernels (mega.hip), cross-attention combines in-kernel
         const bool wg_attn = c.wg_attn && n <= 5 && ceil_div(n_ctx, splits) <= MEGA_CROSS_PER_MAX;

@@ -70,6 +70,60 @@ __global__ __launch_bounds__(256) void convert_kernel(const TS *__restrict__ src
     }
 }
 
+// GGML block-quantised tensor types (ggml.h of the whisper.cpp v1.6.2 era): 32 elements per block
+//   q4_0 {f16 d; u8 qs[16]}            x = (nibble - 8) * d
+//   q4_1 {f16 d; f16 m; u8 qs[16]}     x = nibble * d + m
+//   q5_0 {f16 d; u8 qh[4]; u8 qs[16]}  x = ((nibble | bit << 4) - 16) * d
+//   q5_1 {f16 d; f16 m; u8 qh[4]; u8 qs[16]}  x = (nibble | bit << 4) * d + m
+//   q8_0 {f16 d; i8 qs[32]}            x = qs * d
+// element j < 16 of a block takes the low nibble of qs[j], element j + 16 the high nibble; its fifth bit is bit j
+// (resp. j + 16) of qh.  Dequantised once at load into the compute type: the engine has no quantised matmul.
+enum { TYPE_Q4_0 = 2, TYPE_Q4_1 = 3, TYPE_Q5_0 = 6, TYPE_Q5_1 = 7, TYPE_Q8_0 = 8 };
+inline int quant_block_bytes(int type) {
+    switch (type) {
+    case TYPE_Q4_0: return 18;
+    case TYPE_Q4_1: return 20;
+    case TYPE_Q5_0: return 22;
+    case TYPE_Q5_1: return 24;
+    case TYPE_Q8_0: return 34;
+    default: return 0;
+    }
+}
+
+template <typename TD>
+__global__ __launch_bounds__(256) void dequant_kernel(const unsigned char *__restrict__ src, TD *__restrict__ dst, size_t n,
+                                                      int type, int block_bytes) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const unsigned char *b = src + (i >> 5) * block_bytes;
+        const int j = (int)(i & 31);
+        const float d = __half2float(*reinterpret_cast<const __half *>(b));
+        float v;
+        if (type == TYPE_Q8_0) {
+            v = d * (float)(signed char)b[2 + j];
+        } else {
+            const bool has_m = type == TYPE_Q4_1 || type == TYPE_Q5_1, has_h = type == TYPE_Q5_0 || type == TYPE_Q5_1;
+            const unsigned char *q = b + 2 + (has_m ? 2 : 0);
+            int x;
+            if (has_h) {
+                const unsigned qh = (unsigned)q[0] | ((unsigned)q[1] << 8) | ((unsigned)q[2] << 16) | ((unsigned)q[3] << 24);
+                const unsigned char byte = q[4 + (j & 15)];
+                x = (j < 16 ? (byte & 0x0F) : (byte >> 4)) | (int)(((qh >> j) & 1u) << 4);
+            } else {
+                const unsigned char byte = q[j & 15];
+                x = j < 16 ? (byte & 0x0F) : (byte >> 4);
+            }
+            if (has_m) v = (float)x * d + __half2float(*reinterpret_cast<const __half *>(b + 2));
+            else v = (float)(x - (has_h ? 16 : 8)) * d;
+        }
+        if constexpr (sizeof(TD) == 2) {
+            __hip_bfloat16 h = __float2bfloat16(v);
+            dst[i] = *reinterpret_cast<bf16_t *>(&h);
+        } else {
+            dst[i] = v;
+        }
+    }
+}
+
 struct Loader {
     Model &m;
     std::map<std::string, TensorRef> dir;
@@ -92,11 +146,20 @@ struct Loader {
     // copy tensor `name` (n elements) converted to `dt` at dst (+ element offset)
     void put(const std::string &name, size_t n, void *dst, DType dt, int conv_ci = 0) {
         const TensorRef &t = get(name, n);
-        const size_t bytes = n * (t.type == TYPE_F16 ? 2 : 4);
+        const int qb = quant_block_bytes(t.type);
+        const size_t bytes = qb ? n / 32 * qb : n * (t.type == TYPE_F16 ? 2 : 4);
         MW_CHECK(bytes <= staging_size, "staging too small");
         MW_HIP(hipMemcpyAsync(staging, t.data, bytes, hipMemcpyHostToDevice, st));
         dim3 grid((unsigned)std::min<size_t>(ceil_div<size_t>(n, 256), 8192));
-        if (t.type == TYPE_F16) {
+        if (qb) {
+            MW_CHECK(conv_ci == 0, "quantised convolution weights are not a GGML whisper layout");
+            if (dt == DType::BF16)
+                hipLaunchKernelGGL(dequant_kernel<bf16_t>, grid, dim3(256), 0, st, (const unsigned char *)staging, (bf16_t *)dst, n,
+                                   t.type, qb);
+            else
+                hipLaunchKernelGGL(dequant_kernel<float>, grid, dim3(256), 0, st, (const unsigned char *)staging, (float *)dst, n,
+                                   t.type, qb);
+        } else if (t.type == TYPE_F16) {
             if (dt == DType::BF16)
                 hipLaunchKernelGGL((convert_kernel<uint16_t, bf16_t>), grid, dim3(256), 0, st, (const uint16_t *)staging,
                                    (bf16_t *)dst, n, conv_ci, 1.0f);
@@ -289,9 +352,12 @@ void load_model(Model &m, const unsigned char *data, size_t size, DType wt, hipS
             t.n *= (size_t)ne;
         }
         std::string name((const char *)c.take(name_len), name_len);
-        if (ttype != TYPE_F32 && ttype != TYPE_F16)
-            throw std::runtime_error("tensor " + name + ": quantised GGML types are not supported yet (f32/f16 only)");
-        const size_t bytes = t.n * (ttype == TYPE_F16 ? 2 : 4);
+        const int qb = quant_block_bytes(ttype);
+        if (ttype != TYPE_F32 && ttype != TYPE_F16 && qb == 0)
+            throw std::runtime_error("tensor " + name + ": unsupported GGML tensor type " + std::to_string(ttype) +
+                                     " (f32, f16, q4_0, q4_1, q5_0, q5_1, q8_0 are read)");
+        if (qb && (t.ne[0] % 32 != 0)) throw std::runtime_error("tensor " + name + ": quantised row length is not a multiple of 32");
+        const size_t bytes = qb ? t.n / 32 * qb : t.n * (ttype == TYPE_F16 ? 2 : 4);
         t.data = c.take(bytes);
         max_bytes = std::max(max_bytes, bytes);
         L.dir[name] = std::move(t);

@@ -307,6 +307,52 @@ bool load_model(const char *path, Model &m) {
             std::vector<uint16_t> h(n);
             if (fread(h.data(), 2, n, f) != n) r.ok = false;
             for (size_t i = 0; i < n; ++i) t.d[i] = half_to_float(h[i]);
+        } else if (ttype == 2 || ttype == 3 || ttype == 6 || ttype == 7 || ttype == 8) {
+            // GGML block-quantised types (32 elements per block), dequantised the way ggml's dequantize_row_q* do:
+            // q4_0 {f16 d; qs[16]} (nib-8)*d | q4_1 {d; m; qs} nib*d+m | q5_0 {d; qh[4]; qs} ((nib|bit<<4)-16)*d |
+            // q5_1 {d; m; qh; qs} (nib|bit<<4)*d+m | q8_0 {d; i8 qs[32]} qs*d
+            const int bb = ttype == 2 ? 18 : ttype == 3 ? 20 : ttype == 6 ? 22 : ttype == 7 ? 24 : 34;
+            if (n % 32 != 0) r.ok = false;
+            std::vector<unsigned char> raw(n / 32 * bb);
+            if (r.ok && fread(raw.data(), 1, raw.size(), f) != raw.size()) r.ok = false;
+            for (size_t blk = 0; r.ok && blk < n / 32; ++blk) {
+                const unsigned char *b = raw.data() + blk * bb;
+                uint16_t dh, mh = 0;
+                memcpy(&dh, b, 2);
+                const float d = half_to_float(dh);
+                float *y = t.d.data() + blk * 32;
+                if (ttype == 8) {
+                    for (int j = 0; j < 32; ++j) y[j] = (float)(int8_t)b[2 + j] * d;
+                    continue;
+                }
+                const bool has_m = ttype == 3 || ttype == 7, has_h = ttype == 6 || ttype == 7;
+                const unsigned char *q = b + 2;
+                if (has_m) {
+                    memcpy(&mh, q, 2);
+                    q += 2;
+                }
+                const float mn = half_to_float(mh);
+                uint32_t qh = 0;
+                if (has_h) {
+                    memcpy(&qh, q, 4);
+                    q += 4;
+                }
+                for (int j = 0; j < 16; ++j) {
+                    int x0 = q[j] & 0x0F, x1 = q[j] >> 4;
+                    if (has_h) {
+                        x0 |= (int)((qh >> j) & 1u) << 4;
+                        x1 |= (int)((qh >> (j + 16)) & 1u) << 4;
+                    }
+                    if (has_m) {
+                        y[j] = (float)x0 * d + mn;
+                        y[j + 16] = (float)x1 * d + mn;
+                    } else {
+                        const int zero = has_h ? 16 : 8;
+                        y[j] = (float)(x0 - zero) * d;
+                        y[j + 16] = (float)(x1 - zero) * d;
+                    }
+                }
+            }
         } else {
             fprintf(stderr, "oracle: unsupported tensor type %d (%s)\n", ttype, name.c_str());
             r.ok = false;

@@ -205,6 +205,81 @@ def synthetic_tensors(hp: HParams, seed: int = 1234, sigma: float = 0.02,
 
 
 # --------------------------------------------------------------------------------------------
+# GGML block quantisation (32 elements per block), as the catalogue's q4/q5/q8 model files use it
+# --------------------------------------------------------------------------------------------
+GGML_TYPE_Q4_0, GGML_TYPE_Q4_1, GGML_TYPE_Q5_0, GGML_TYPE_Q5_1, GGML_TYPE_Q8_0 = 2, 3, 6, 7, 8
+QUANT_BLOCK_BYTES = {GGML_TYPE_Q4_0: 18, GGML_TYPE_Q4_1: 20, GGML_TYPE_Q5_0: 22, GGML_TYPE_Q5_1: 24, GGML_TYPE_Q8_0: 34}
+# hparams.ftype (enum ggml_ftype) -> tensor type of the quantised matrices
+FTYPE_TO_QTYPE = {2: GGML_TYPE_Q4_0, 3: GGML_TYPE_Q4_1, 7: GGML_TYPE_Q8_0, 8: GGML_TYPE_Q5_0, 9: GGML_TYPE_Q5_1}
+
+
+def quantize_blocks(a: np.ndarray, qtype: int) -> bytes:
+    """Reference-style quantisation of a float32 array (size % 32 == 0) into GGML blocks."""
+    x = np.ascontiguousarray(a, np.float32).reshape(-1, 32)
+    nblk = x.shape[0]
+    out = np.zeros((nblk, QUANT_BLOCK_BYTES[qtype]), np.uint8)
+    if qtype == GGML_TYPE_Q8_0:
+        d = np.abs(x).max(axis=1) / 127.0
+        inv = np.where(d > 0, 1.0 / np.where(d > 0, d, 1), 0).astype(np.float32)
+        q = np.clip(np.round(x * inv[:, None]), -127, 127).astype(np.int8)
+        out[:, 0:2] = d.astype("<f2").view(np.uint8).reshape(nblk, 2)
+        out[:, 2:] = q.view(np.uint8)
+        return out.tobytes()
+    sym = qtype in (GGML_TYPE_Q4_0, GGML_TYPE_Q5_0)
+    levels = 16 if qtype in (GGML_TYPE_Q4_0, GGML_TYPE_Q4_1) else 32
+    if sym:  # d = (value of largest magnitude) / -(levels/2)
+        idx = np.abs(x).argmax(axis=1)
+        mx = x[np.arange(nblk), idx]
+        d = mx / -(levels // 2)
+        inv = np.where(d != 0, 1.0 / np.where(d != 0, d, 1), 0).astype(np.float32)
+        q = np.minimum(levels - 1, (x * inv[:, None] + (levels // 2 + 0.5)).astype(np.int32)).clip(0, levels - 1)
+        head = d.astype("<f2").view(np.uint8).reshape(nblk, 2)
+        pos = 2
+    else:
+        mn, mxv = x.min(axis=1), x.max(axis=1)
+        d = (mxv - mn) / (levels - 1)
+        inv = np.where(d != 0, 1.0 / np.where(d != 0, d, 1), 0).astype(np.float32)
+        q = np.minimum(levels - 1, ((x - mn[:, None]) * inv[:, None] + 0.5).astype(np.int32)).clip(0, levels - 1)
+        head = np.concatenate([d.astype("<f2").view(np.uint8).reshape(nblk, 2), mn.astype("<f2").view(np.uint8).reshape(nblk, 2)], axis=1)
+        pos = 4
+    out[:, :pos] = head
+    if levels == 32:
+        bits = ((q >> 4) & 1).astype(np.uint32)
+        qh = (bits << np.arange(32, dtype=np.uint32)[None, :]).sum(axis=1).astype("<u4")
+        out[:, pos:pos + 4] = qh.view(np.uint8).reshape(nblk, 4)
+        pos += 4
+    out[:, pos:pos + 16] = ((q[:, :16] & 0xF) | ((q[:, 16:] & 0xF) << 4)).astype(np.uint8)
+    return out.tobytes()
+
+
+def dequantize_blocks(buf, qtype: int, n: int, off: int = 0) -> np.ndarray:
+    """GGML blocks -> float32 (numpy restatement of ggml's dequantize_row_q*)."""
+    bb = QUANT_BLOCK_BYTES[qtype]
+    nblk = n // 32
+    b = np.frombuffer(buf, np.uint8, nblk * bb, off).reshape(nblk, bb)
+    d = b[:, 0:2].copy().view("<f2").astype(np.float32)  # [nblk, 1]
+    if qtype == GGML_TYPE_Q8_0:
+        return (b[:, 2:].copy().view(np.int8).astype(np.float32) * d).reshape(-1)
+    has_m = qtype in (GGML_TYPE_Q4_1, GGML_TYPE_Q5_1)
+    has_h = qtype in (GGML_TYPE_Q5_0, GGML_TYPE_Q5_1)
+    pos = 2
+    m = 0.0
+    if has_m:
+        m = b[:, 2:4].copy().view("<f2").astype(np.float32)
+        pos = 4
+    hi = np.zeros((nblk, 32), np.int32)
+    if has_h:
+        qh = b[:, pos:pos + 4].copy().view("<u4").astype(np.uint32)  # [nblk, 1]
+        hi = ((qh >> np.arange(32, dtype=np.uint32)[None, :]) & 1).astype(np.int32) << 4
+        pos += 4
+    qs = b[:, pos:pos + 16].astype(np.int32)
+    x = np.concatenate([qs & 0xF, qs >> 4], axis=1) | hi
+    if has_m:
+        return (x.astype(np.float32) * d + m).reshape(-1)
+    return ((x - (16 if has_h else 8)).astype(np.float32) * d).reshape(-1)
+
+
+# --------------------------------------------------------------------------------------------
 # writer / reader
 # --------------------------------------------------------------------------------------------
 def write_ggml(path: str, hp: HParams, tensors: Dict[str, np.ndarray], vocab: List[bytes] | None = None,
@@ -225,14 +300,17 @@ def write_ggml(path: str, hp: HParams, tensors: Dict[str, np.ndarray], vocab: Li
             f.write(w)
         for name, shape, is_mat in tensor_shapes(hp):
             a = np.ascontiguousarray(tensors[name], dtype=np.float32).reshape(shape)
-            use_f16 = hp.ftype == 1 and is_mat
-            ttype = GGML_TYPE_F16 if use_f16 else GGML_TYPE_F32
+            qtype = FTYPE_TO_QTYPE.get(hp.ftype % 1000)
+            # quantised files: every 2-d weight is quantised, the (3-d) conv weights stay f16, vectors f32
+            quant = qtype is not None and is_mat and len(shape) == 2 and shape[-1] % 32 == 0
+            use_f16 = is_mat and not quant and hp.ftype % 1000 != 0
+            ttype = qtype if quant else (GGML_TYPE_F16 if use_f16 else GGML_TYPE_F32)
             ne = list(reversed(shape))  # ggml order: ne[0] is the fastest dimension
             nb = name.encode()
             f.write(struct.pack("<iii", len(ne), len(nb), ttype))
             f.write(struct.pack("<%di" % len(ne), *ne))
             f.write(nb)
-            f.write(a.astype("<f2" if use_f16 else "<f4").tobytes())
+            f.write(quantize_blocks(a, qtype) if quant else a.astype("<f2" if use_f16 else "<f4").tobytes())
 
 
 def read_ggml(path: str):
@@ -256,7 +334,9 @@ def read_ggml(path: str):
         ne = struct.unpack_from("<%di" % n_dims, buf, off); off += 4 * n_dims
         name = buf[off:off + name_len].decode(); off += name_len
         n = int(np.prod(ne))
-        if ttype == GGML_TYPE_F16:
+        if ttype in QUANT_BLOCK_BYTES:
+            a = dequantize_blocks(buf, ttype, n, off); off += n // 32 * QUANT_BLOCK_BYTES[ttype]
+        elif ttype == GGML_TYPE_F16:
             a = np.frombuffer(buf, "<f2", n, off).astype(np.float32); off += 2 * n
         else:
             a = np.frombuffer(buf, "<f4", n, off).astype(np.float32); off += 4 * n
