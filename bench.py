@@ -15,9 +15,10 @@ random weights would otherwise stop after a handful of tokens), and temperature 
 collective; value = all ranks' audio seconds / max-over-ranks time; scaling "weak".
 
 One JSON line on rank 0 (see the contract in the task statement) with two extra objects:
-  roofline     the dominant kernel (a weight-streaming projection class of the decode step): algorithmic
-               bytes per launch / average launch duration measured live with HIP events on the engine's
-               stream during the timed region, against 8 TB/s HBM
+  roofline     the dominant kernel class of the decode step by share of kernel time (cross-attention; further
+               classes under roofline_others): algorithmic bytes per launch / average launch duration measured
+               live with HIP events on the engine's stream in a launch-by-launch pass right after the timed
+               region (the timed region itself replays captured graphs), against 8 TB/s HBM
   cpu_baseline the CPU oracle (a port, NOT whisper.cpp) timed on the box's host cores on a bounded sample
 """
 from __future__ import annotations
@@ -46,11 +47,17 @@ def load_package():
     return mod
 
 
-GEMV_CLASSES = {"qkv": 0, "attn_out": 1, "cross_q": 2, "fc1": 3, "fc2": 4, "logits": 5}
+GEMV_CLASSES = {"qkv": 0, "attn_out": 1, "cross_q": 2, "fc1": 3, "fc2": 4, "logits": 5, "cross_attn": 7}
+KERNEL_NAMES = {"qkv": "proj_wg_kernel<rows,LN,EPI_QKV>", "cross_q": "proj_wg_kernel<rows,LN,EPI_SCALE>",
+                "fc1": "proj_wg_kernel<rows,LN,EPI_GELU>", "attn_out": "gemv_kernel<bf16,class=attn_out>",
+                "fc2": "gemv_kernel<bf16,class=fc2>", "logits": "gemv_kernel<bf16,class=logits>",
+                "cross_attn": "cross_attn_wg_kernel<rows>"}
 
 
-def gemv_bytes(cls: str, d: int, n_vocab: int, rows: int, wbytes: int) -> int:
-    """Algorithmic HBM bytes of ONE launch of a projection class."""
+def gemv_bytes(cls: str, d: int, n_vocab: int, rows: int, wbytes: int, n_audio_ctx: int = 1500) -> int:
+    """Algorithmic HBM bytes of ONE launch of a decode-step kernel class."""
+    if cls == "cross_attn":  # one layer's cross K and V of the stream (shared by the rows) + q in + rows out
+        return 2 * n_audio_ctx * d * wbytes + rows * d * 4 * 2
     N, K = {"qkv": (3 * d, d), "attn_out": (d, d), "cross_q": (d, d), "fc1": (4 * d, d), "fc2": (d, 4 * d),
             "logits": (n_vocab, d)}[cls]
     resid = cls in ("attn_out", "fc2")
@@ -96,7 +103,10 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--beam", type=int, default=5)
     ap.add_argument("--decode-steps", type=int, default=128)
-    ap.add_argument("--roofline-class", default="fc2", choices=sorted(GEMV_CLASSES))
+    ap.add_argument("--roofline-class", default="cross_attn", choices=sorted(GEMV_CLASSES),
+                    help="kernel class of the roofline object (default: the class with the largest share of kernel time "
+                         "in profiles/r01_kernel_stats_graph_wg.csv)")
+    ap.add_argument("--roofline-others", default="fc2,fc1,qkv", help="further classes reported under roofline_others")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-steps", type=int, default=12)
     ap.add_argument("--model-dir", default=os.environ.get("MI355_WHISPER_BENCH_DIR", "/tmp/mi355_whisper_bench"))
@@ -173,23 +183,31 @@ def main():
         from tools import stream_shard
         elapsed = stream_shard.max_over_ranks(dist, elapsed, device=f"cuda:{local_rank}")
 
-    # roofline leg: the same step, launch by launch (graphs off while a projection class is bracketed by
-    # HIP events on the engine's stream), right after the timed region, same process, same weights
-    n_launch, tot_ms = C.c_int(0), C.c_float(0)
+    # roofline leg: the same step, launch by launch (graphs off while a kernel class is bracketed by HIP events on
+    # the engine's stream), right after the timed region, same process, same weights
+    prof = {}
     if rank == 0:
-        eng.L.mw_profile_begin(eng.ctx, GEMV_CLASSES[cls], 200000)
-        for _ in range(max(1, min(a.steps, 2))):
-            step()
-        eng.L.mw_profile_end(eng.ctx, C.byref(n_launch), C.byref(tot_ms))
+        for k in [cls] + [x for x in a.roofline_others.split(",") if x and x != cls]:
+            n_launch, tot_ms = C.c_int(0), C.c_float(0)
+            eng.L.mw_profile_begin(eng.ctx, GEMV_CLASSES[k], 200000)
+            for _ in range(max(1, min(a.steps, 2))):
+                step()
+            eng.L.mw_profile_end(eng.ctx, C.byref(n_launch), C.byref(tot_ms))
+            prof[k] = (n_launch.value, tot_ms.value)
     if rank == 0:
         audio_s = 30.0 * a.steps * n_gpus
         value = audio_s / elapsed
         ms_per_step = 1000.0 * elapsed / a.steps
         wbytes = 2 if a.precision == "bf16" else 4
         rows = a.beam
-        b_launch = gemv_bytes(cls, eng.n_text_state, eng.n_vocab, rows, wbytes)
-        avg_ms = tot_ms.value / max(n_launch.value, 1)
-        achieved = b_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        def roof(k):
+            n_l, ms = prof[k]
+            b_launch = gemv_bytes(k, eng.n_text_state, eng.n_vocab, rows, wbytes)
+            avg_ms = ms / max(n_l, 1)
+            achieved = b_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            return {"bound": "hbm", "kernel": KERNEL_NAMES[k], "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+                    "frac": round(achieved / 8000.0, 4), "traffic": None, "bytes_per_launch": b_launch,
+                    "avg_launch_us": round(avg_ms * 1000.0, 3), "launches_timed": n_l}
         out = {
             "metric": "audio-sec transcribed/sec", "value": round(value, 2), "unit": "audio-sec/sec",
             "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -204,11 +222,8 @@ def main():
                                       "decode": round(tm.decode_ms / a.steps, 3), "rules+sample(sync)": round(tm.sample_ms / a.steps, 3),
                                       "decode_calls": tm.n_decode // max(a.steps, 1)},
             "model_load_s": round(t_load, 2),
-            "roofline": {"bound": "hbm", "kernel": f"gemv_kernel<{a.precision},NB={rows},class={cls}>",
-                         "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(achieved / 8000.0, 4), "traffic": None,
-                         "bytes_per_launch": b_launch, "avg_launch_us": round(avg_ms * 1000.0, 3),
-                         "launches_timed": n_launch.value},
+            "roofline": roof(cls),
+            "roofline_others": {k: roof(k) for k in prof if k != cls},
         }
         if not a.no_cpu_baseline and n_gpus == 1:
             threads = min(16, os.cpu_count() or 1)

@@ -84,10 +84,14 @@ int mw_bench_decode_step(struct whisper_context *ctx, int rows, int n_past, int 
 int mw_bench_mel(struct whisper_context *ctx, int n_samples, int iters, float *ms_per_call);
 int mw_bench_encode(struct whisper_context *ctx, int iters, float *ms_per_call);
 
-/* Live timing of ONE projection class of the decode step (the weight-streaming kernels of dec.hip):
-   between begin and end every launch of that class on the context's stream is bracketed by HIP events;
-   end returns the launch count and the summed elapsed time.  Classes: */
-enum mw_gemv_class { MW_GEMV_QKV = 0, MW_GEMV_ATTN_OUT = 1, MW_GEMV_CROSS_Q = 2, MW_GEMV_FC1 = 3, MW_GEMV_FC2 = 4, MW_GEMV_LOGITS = 5 };
+/* Live timing of ONE kernel class of the decode step (the projections of dec.hip / mega.hip and the two
+   attention kernels): between begin and end every launch of that class on the context's stream is bracketed
+   by HIP events (the step then runs launch by launch, not as a captured graph); end returns the launch count
+   and the summed elapsed time.  Classes: */
+enum mw_gemv_class {
+    MW_GEMV_QKV = 0, MW_GEMV_ATTN_OUT = 1, MW_GEMV_CROSS_Q = 2, MW_GEMV_FC1 = 3, MW_GEMV_FC2 = 4, MW_GEMV_LOGITS = 5,
+    MW_STEP_SELF_ATTN = 6, MW_STEP_CROSS_ATTN = 7
+};
 int mw_profile_begin(struct whisper_context *ctx, int gemv_class, int max_launches);
 int mw_profile_end(struct whisper_context *ctx, int *n_launches, float *total_ms);
 

@@ -535,7 +535,7 @@ int mw_set_force_decode_steps(struct whisper_context *ctx, int n) {
 }
 
 int mw_profile_begin(struct whisper_context *ctx, int gemv_class, int max_launches) {
-    if (!ctx || !ctx->c || gemv_class < 0 || gemv_class >= GEMV_N_TAGS || max_launches <= 0 || max_launches > (1 << 20)) return -1;
+    if (!ctx || !ctx->c || gemv_class < 0 || gemv_class >= GEMV_N_TAGS + 2 || max_launches <= 0 || max_launches > (1 << 20)) return -1;
     return guarded("mw_profile_begin", [&]() {
         Context &c = *ctx->c;
         DeviceGuard g(c);

@@ -414,12 +414,17 @@ void decode(Context &c, const int *tokens, const int *pos, const int *slot, int 
                 g.kv_t = wt; g.d_slot = c.d_slot; g.d_pos = c.d_pos; g.n_text_ctx = TC; g.tag = GEMV_QKV;
                 gemv(g);
             }
-            if (wg_attn)
-                launch_self_attn_wg(c.d_q, (char *)c.d_kself + l * kv_layer, (char *)c.d_vself + l * kv_layer, c.d_slot, c.d_pos,
-                                    c.d_kv_idx[c.kv_cur], c.d_attd, act_t, n, H, d, TC, st);
-            else
-                launch_self_attn(c.d_q, (char *)c.d_kself + l * kv_layer, (char *)c.d_vself + l * kv_layer, wt, c.d_slot, c.d_pos,
-                                 c.d_kv_idx[c.kv_cur], c.d_attd, act_t, n, H, d, TC, st);
+            {
+                const bool prof = c.prof_tag == GEMV_N_TAGS && c.prof_n + 2 <= (int)c.prof_ev.size();
+                if (prof) MW_HIP(hipEventRecord(c.prof_ev[c.prof_n++], st));
+                if (wg_attn)
+                    launch_self_attn_wg(c.d_q, (char *)c.d_kself + l * kv_layer, (char *)c.d_vself + l * kv_layer, c.d_slot, c.d_pos,
+                                        c.d_kv_idx[c.kv_cur], c.d_attd, act_t, n, H, d, TC, st);
+                else
+                    launch_self_attn(c.d_q, (char *)c.d_kself + l * kv_layer, (char *)c.d_vself + l * kv_layer, wt, c.d_slot, c.d_pos,
+                                     c.d_kv_idx[c.kv_cur], c.d_attd, act_t, n, H, d, TC, st);
+                if (prof) MW_HIP(hipEventRecord(c.prof_ev[c.prof_n++], st));
+            }
             {
                 GemvArgs g;
                 g.x = (const float *)c.d_attd; g.x_bf16 = mf; g.ldx = d; g.n = n; g.W = e.out_w; g.bias = e.out_b; g.N = d; g.K = d;
@@ -433,12 +438,17 @@ void decode(Context &c, const int *tokens, const int *pos, const int *slot, int 
                 gemv(g);
             }
             const char *ck = (const char *)c.d_cross + (size_t)l * 2 * hp.n_audio_ctx * d * ws;
-            if (wg_attn)
-                launch_cross_attn_wg(c.d_q, ck, ck + (size_t)hp.n_audio_ctx * d * ws, c.d_part, c.d_attd, act_t, c.d_head_cnt, n, H, d,
-                                     n_ctx, splits, st);
-            else
-                launch_cross_attn(c.d_q, ck, ck + (size_t)hp.n_audio_ctx * d * ws, wt, c.d_part, c.d_attd, act_t, n, H, d, n_ctx,
-                                  splits, st);
+            {
+                const bool prof = c.prof_tag == GEMV_N_TAGS + 1 && c.prof_n + 2 <= (int)c.prof_ev.size();
+                if (prof) MW_HIP(hipEventRecord(c.prof_ev[c.prof_n++], st));
+                if (wg_attn)
+                    launch_cross_attn_wg(c.d_q, ck, ck + (size_t)hp.n_audio_ctx * d * ws, c.d_part, c.d_attd, act_t, c.d_head_cnt, n, H, d,
+                                         n_ctx, splits, st);
+                else
+                    launch_cross_attn(c.d_q, ck, ck + (size_t)hp.n_audio_ctx * d * ws, wt, c.d_part, c.d_attd, act_t, n, H, d, n_ctx,
+                                      splits, st);
+                if (prof) MW_HIP(hipEventRecord(c.prof_ev[c.prof_n++], st));
+            }
             {
                 GemvArgs g;
                 g.x = (const float *)c.d_attd; g.x_bf16 = mf; g.ldx = d; g.n = n; g.W = e.co_w; g.bias = e.co_b; g.N = d; g.K = d;
@@ -1029,7 +1039,9 @@ int full(Context &c, whisper_full_params params, const float *samples, int n_sam
                         params.new_segment_callback(nullptr, nullptr, 1, params.new_segment_callback_user_data);
                 }
             }
-            seek += seek_delta;
+            // forced decode length (bench-only extension): the window always advances as a whole, so one call over
+            // 30 s of audio is exactly one encoder pass + fds decode steps
+            seek += fds > 0 ? 100 * WHISPER_CHUNK_SIZE : seek_delta;
         }
     }
     c.tm.total_ms += now_ms() - t_start;

@@ -1274,7 +1274,9 @@ int full(ow_context &c, ow_params params, const float *samples, int n_samples) {
                     for (int j = i0; j < (int)tokens_cur.size(); ++j) result_all.back().tokens.push_back(tokens_cur[j]);
                 }
             }
-            seek += seek_delta;
+            // forced decode length (bench-only extension): the window always advances as a whole, so one call over
+            // 30 s of audio is exactly one encoder pass + fds decode steps
+            seek += fds > 0 ? 100 * CHUNK_SIZE : seek_delta;
         }
     }
     return 0;

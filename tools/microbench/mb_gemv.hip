@@ -48,6 +48,23 @@ template <typename F> float time_it(hipStream_t st, int iters, F &&f) {
     return ms * 1000.0f / iters;
 }
 
+// few workgroups, each streaming a large contiguous slab: how fast can ONE CU pull from HBM?
+template <int T, int NL>
+__global__ __launch_bounds__(T) void slab_stream(const unsigned short *W, long slab_elems, float *out) {
+    const unsigned short *base = W + (long)blockIdx.x * slab_elems;
+    u32x4 v[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const long e = ((long)i * T + threadIdx.x) * 8;
+        v[i] = u32x4{0, 0, 0, 0};
+        if (e < slab_elems) v[i] = __builtin_nontemporal_load((const u32x4 *)(base + e));
+    }
+    unsigned s = 0;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) s += v[i].x ^ v[i].y ^ v[i].z ^ v[i].w;
+    if (s == 0x12345678u) out[threadIdx.x] = 1.0f;
+}
+
 int main(int argc, char **argv) {
     const int d = 1280, L = 32, rows = argc > 1 ? atoi(argv[1]) : 5;
     hipStream_t st;
@@ -123,6 +140,17 @@ int main(int argc, char **argv) {
         printf("floor N=4d K=d R=4       : %7.2f us  %7.1f GB/s\n", us, (double)4 * d * d * 2 / us / 1e3);
         us = time_it(st, 200, [&](int i) { hipLaunchKernelGGL((stream_floor<1, 10>), dim3(d / 4), dim3(256), 0, st, W + per * (i % L), d, 4 * d, out); });
         printf("floor N=d K=4d R=1       : %7.2f us  %7.1f GB/s\n", us, (double)4 * d * d * 2 / us / 1e3);
+        {
+            const long slab = 384 * 1024 / 2;  // 384 KB per workgroup (one head's cross K+V)
+            float u2 = time_it(st, 200, [&](int i) { hipLaunchKernelGGL((slab_stream<1024, 24>), dim3(20), dim3(1024), 0, st, W + per * (i % L), slab, out); });
+            printf("slab 20 wg x 384 KB (1024 thr): %7.2f us  %7.1f GB/s per wg\n", u2, 384.0 * 1024 / u2 / 1e3);
+            u2 = time_it(st, 200, [&](int i) { hipLaunchKernelGGL((slab_stream<1024, 12>), dim3(40), dim3(1024), 0, st, W + per * (i % L), slab / 2, out); });
+            printf("slab 40 wg x 192 KB (1024 thr): %7.2f us  %7.1f GB/s per wg\n", u2, 192.0 * 1024 / u2 / 1e3);
+            u2 = time_it(st, 200, [&](int i) { hipLaunchKernelGGL((slab_stream<512, 12>), dim3(80), dim3(512), 0, st, W + per * (i % L), slab / 4, out); });
+            printf("slab 80 wg x  96 KB ( 512 thr): %7.2f us  %7.1f GB/s per wg\n", u2, 96.0 * 1024 / u2 / 1e3);
+            u2 = time_it(st, 200, [&](int i) { hipLaunchKernelGGL((slab_stream<512, 4>), dim3(240), dim3(512), 0, st, W + per * (i % L), slab / 12, out); });
+            printf("slab 240 wg x 32 KB ( 512 thr): %7.2f us  %7.1f GB/s per wg\n", u2, 32.0 * 1024 / u2 / 1e3);
+        }
         us = time_it(st, 200, [&](int i) { hipLaunchKernelGGL((stream_floor<1, 1>), dim3(1), dim3(64), 0, st, W, 1, 8, out); });
         printf("empty-ish kernel         : %7.2f us\n", us);
     }
