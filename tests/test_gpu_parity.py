@@ -491,3 +491,44 @@ def test_model_dir_and_bad_files(pkg, model_file, tmp_path):
     eng = pkg.Engine("", ctx=ctx)
     assert eng.mel(ggml_io.synth_pcm(0, 1.5)).shape[0] == 80
     L.whisper_free(ctx)
+
+
+# ---------------------------------------------------------------------------------------------
+# whisper_full_params fields LocalVocal fills from its settings (whisper-params.cpp:102-144): every field the
+# engine honours changes the result the same way it does in the restatement
+# ---------------------------------------------------------------------------------------------
+_VARIANTS = [
+    ("micro.en", 0, dict(no_timestamps=True)),
+    ("micro.en", 0, dict(single_segment=True)),
+    ("micro.en", 0, dict(max_tokens=5)),
+    ("micro.en", 0, dict(audio_ctx=750)),
+    ("micro.en", 0, dict(offset_ms=2000, duration_ms=5000)),
+    ("micro.en", 0, dict(initial_prompt=" hello there. and so on", n_max_text_ctx=16)),
+    ("micro.en", 0, dict(suppress_non_speech_tokens=True, suppress_blank=False)),
+    ("micro.en", 0, dict(suppress_regex="[a-m].*")),
+    ("micro.en", 0, dict(tdrz_enable=True)),
+    ("micro.en", 0, dict(max_initial_ts=0.5)),
+    ("micro.en", 0, dict(temperature=0.4, best_of=3)),
+    ("micro.en", 1, dict(beam_size=3, length_penalty=0.5)),
+    ("micro.en", 1, dict(beam_size=2, no_timestamps=True)),
+    ("micro", 0, dict(language="de", translate=True)),
+    ("micro", 1, dict(language="auto", beam_size=4)),
+    ("micro", 0, dict(detect_language=True, language="auto")),
+]
+
+
+@pytest.mark.parametrize("preset,strategy,kw", _VARIANTS, ids=[f"{p}-{s}-{'-'.join(k)}" for p, s, k in _VARIANTS])
+def test_full_param_variants(pkg, engines, oracles, preset, strategy, kw):
+    eng, orc = engines(preset, pkg.PRECISION_FP32), oracles(preset)
+    pcm = ggml_io.synth_pcm(11, 9.0)
+    args = dict(temperature_inc=0.0, duration_ms=9000)
+    args.update(kw)
+    gs, rs = _run_both(pkg, eng, orc, pcm, strategy, **args)
+    _assert_same_segments(gs, rs)
+    if kw.get("detect_language"):
+        assert rs == []  # whisper_full returns right after the detection (A.6)
+    if "max_tokens" in kw:
+        assert all(len(s["tokens"]) <= kw["max_tokens"] + 1 for s in rs)
+    if kw.get("no_timestamps"):
+        beg = eng.L.whisper_token_beg(eng.ctx)
+        assert all(t["id"] < beg for s in rs for t in s["tokens"])
