@@ -200,13 +200,26 @@ def main():
         ms_per_step = 1000.0 * elapsed / a.steps
         wbytes = 2 if a.precision == "bf16" else 4
         rows = a.beam
+        # HBM bytes per launch from the PMC passes (separate rocprofv3 --pmc runs of this command, summarised by
+        # tools/pmc_summary.py with the gfx950 FETCH_SIZE correction); null when the summary is not in the tree
+        pmc = {}
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+                pmc = json.load(fh).get("kernels", {})
+        except (OSError, ValueError):
+            pmc = {}
+
         def roof(k):
             n_l, ms = prof[k]
             b_launch = gemv_bytes(k, eng.n_text_state, eng.n_vocab, rows, wbytes)
             avg_ms = ms / max(n_l, 1)
             achieved = b_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
             return {"bound": "hbm", "kernel": KERNEL_NAMES[k], "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                    "frac": round(achieved / 8000.0, 4), "traffic": None, "bytes_per_launch": b_launch,
+                    "frac": round(achieved / 8000.0, 4),
+                    "traffic": (pmc[k]["hbm_bytes_per_launch"] if k in pmc and a.model == "large-v3" and a.beam == 5 and
+                                a.precision == "bf16" else None),
+                    "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)",
+                    "bytes_per_launch": b_launch,
                     "avg_launch_us": round(avg_ms * 1000.0, 3), "launches_timed": n_l}
         out = {
             "metric": "audio-sec transcribed/sec", "value": round(value, 2), "unit": "audio-sec/sec",
