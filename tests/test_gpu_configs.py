@@ -1,0 +1,77 @@
+"""GPU: the BASELINE.json / SURVEY.md §8(d) configurations that are parity cases rather than bench lines, at the real
+model dimensions (seeded synthetic weights in the GGML container; no checkpoints exist offline).
+
+  configs[0]  tiny.en dims, 30 s, greedy, the offline-test parameter set (localvocal-offline-test.cpp:176-200)
+  configs[1]  base.en dims, greedy fp32, one 30 s window: token ids equal to the oracle's
+  configs[3]  several independent streams per GPU (one context per stream), greedy, partitioned i mod n
+With random weights a window would stop after a few tokens, so the decode length is forced on both sides.
+"""
+import numpy as np
+import pytest
+
+from oracle import pyoracle
+from tools import ggml_io, stream_shard
+
+pytestmark = pytest.mark.gpu
+
+
+def _forced_tokens(pkg, path, pcm, steps, precision, strategy=0, **kw):
+    eng = pkg.Engine(path, precision=precision)
+    try:
+        eng.set_force_decode_steps(steps)
+        p = eng.default_params(strategy, temperature_inc=0.0, duration_ms=int(len(pcm) * 1000 // 16000), **kw)
+        assert eng.full(p, pcm) == 0
+        return eng.token_ids(), eng.segments()
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("preset,steps", [("tiny.en", 64), ("base.en", 48)])
+def test_real_dims_greedy_fp32_tokens_equal_oracle(pkg, model_file, preset, steps):
+    path = model_file(preset, ftype=1)          # f16 matrices, like the catalogue's ggml-*.bin files
+    pcm = ggml_io.synth_pcm(0, 30.0)            # chirps + AM + noise, seed 0, 480 000 samples
+    # offline-test parameter set: greedy, no_context, single language "en", timestamps on
+    kw = dict(language="en", no_context=True, single_segment=False, suppress_blank=True)
+    got, segs = _forced_tokens(pkg, path, pcm, steps, pkg.PRECISION_FP32, **kw)
+    orc = pyoracle.Oracle(path)
+    try:
+        po = orc.default_params(0, temperature_inc=0.0, duration_ms=30000, force_decode_steps=steps,
+                                **{k: (int(v) if isinstance(v, bool) else v) for k, v in kw.items()})
+        assert orc.full(po, pcm) == 0
+        want = orc.token_ids()
+    finally:
+        orc.close()
+    assert len(want) >= steps // 2
+    assert got == want
+    # bf16 mode on the same file: same length, match rate reported (not required to be exact)
+    got16, _ = _forced_tokens(pkg, path, pcm, steps, pkg.PRECISION_BF16, **kw)
+    agree = sum(a == b for a, b in zip(got16, want))
+    print(f"{preset}: bf16 tokens equal to the fp32 oracle at {agree}/{len(want)} positions")
+    assert len(got16) == len(want)
+
+
+def test_independent_streams_one_context_each(pkg, model_file):
+    # configs[3] in miniature: 6 streams, clip seeds 100+i, greedy, forced 24 steps; stream i -> rank i mod n.
+    # Contexts are independent: running them interleaved on one GPU gives each stream the tokens it gets alone.
+    path = model_file("micro", ftype=1)
+    n_streams, steps = 6, 24
+    clips = [ggml_io.synth_pcm(100 + i, 10.0) for i in range(n_streams)]
+    alone = [_forced_tokens(pkg, path, clips[i], steps, pkg.PRECISION_FP32, language="en")[0] for i in range(n_streams)]
+    engs = [pkg.Engine(path, precision=pkg.PRECISION_FP32) for _ in range(n_streams)]
+    try:
+        for e in engs:
+            e.set_force_decode_steps(steps)
+        out = [None] * n_streams
+        for rnd in range(2):  # two rounds, interleaved across contexts
+            for i in (range(n_streams) if rnd == 0 else reversed(range(n_streams))):
+                p = engs[i].default_params(0, temperature_inc=0.0, duration_ms=10000, language="en")
+                assert engs[i].full(p, clips[i]) == 0
+                out[i] = engs[i].token_ids()
+        assert out == alone
+    finally:
+        for e in engs:
+            e.close()
+    # the partition the bench uses over ranks covers every stream exactly once
+    for world in (1, 2, 4, 8):
+        seen = sorted(s for r in range(world) for s in stream_shard.assign_streams(n_streams, world, r))
+        assert seen == list(range(n_streams))
