@@ -75,3 +75,28 @@ def test_independent_streams_one_context_each(pkg, model_file):
     for world in (1, 2, 4, 8):
         seen = sorted(s for r in range(world) for s in stream_shard.assign_streams(n_streams, world, r))
         assert seen == list(range(n_streams))
+
+
+def test_contexts_are_reentrant_across_threads(pkg, model_file):
+    # SURVEY.md §8b threading: one context per OBS source, different sources run concurrently on their own worker
+    # threads; results must not depend on what other contexts are doing.
+    import threading
+    path = model_file("micro.en", ftype=1)
+    clips = [ggml_io.synth_pcm(200 + i, 8.0) for i in range(4)]
+    alone = [_forced_tokens(pkg, path, c, 20, pkg.PRECISION_BF16, strategy=1, language="en")[0] for c in clips]
+    out, errs = [None] * 4, []
+
+    def work(i):
+        try:
+            for _ in range(3):
+                out[i] = _forced_tokens(pkg, path, clips[i], 20, pkg.PRECISION_BF16, strategy=1, language="en")[0]
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    assert out == alone
