@@ -450,10 +450,65 @@ __device__ __forceinline__ void self_attn_phase(const float *q, const bf16_t *kc
     }
 }
 
-// ---- cross-attention: workgroup = (head, key split); all rows share each K/V read; the last split of a head
-// to finish combines the partial softmaxes (no waiting: an arrival counter per head) ----
 constexpr int CPART = 66;
 
+// tail of a cross-attention work item: count this split of head h; the last one to arrive combines the partial
+// softmax records of all splits (fixed split order) into the output rows
+template <int NB, typename OT>
+__device__ __forceinline__ void cross_count_and_combine(const float *part, OT *out, unsigned *head_cnt, float *sc, unsigned *flag,
+                                                        int n, int H, int d, int h, int splits) {
+    const int tid = threadIdx.x;
+        __syncthreads();  // partial stores acknowledged (vmcnt(0)) before this split is counted
+        if (tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(&head_cnt[h], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned last = old == (unsigned)splits - 1;
+            if (last) __hip_atomic_store(&head_cnt[h], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+            *flag = last;
+        }
+        lds_sync();
+        if (*flag) {  // every split of head h is in memory: combine in fixed split order, loads first
+            float *cm = sc, *cl = sc + NB * CROSS_SPLITS_MAX;  // split maxima / sums of all rows, staged in LDS
+            for (int i = tid; i < NB * CROSS_SPLITS_MAX; i += MT) {
+                const int r = i / CROSS_SPLITS_MAX, sidx = i - r * CROSS_SPLITS_MAX;
+                const bool on = r < n && sidx < splits;
+                const float *pp = part + (((long)r * H + h) * splits + (on ? sidx : 0)) * CPART;
+                cm[i] = on ? pp[0] : -INFINITY;
+                cl[i] = on ? pp[1] : 0.0f;
+            }
+            float ov[(NB * 64 + MT - 1) / MT][CROSS_SPLITS_MAX];
+#pragma unroll
+            for (int u = 0; u < (NB * 64 + MT - 1) / MT; ++u) {
+                const int i = tid + u * MT, r = i >> 6, e = i & 63;
+                const bool rowon = i < NB * 64 && r < n;
+                const float *pp = part + ((long)(rowon ? r : 0) * H + h) * splits * CPART;
+#pragma unroll
+                for (int sidx = 0; sidx < CROSS_SPLITS_MAX; ++sidx)
+                    ov[u][sidx] = (rowon && sidx < splits) ? pp[sidx * CPART + 2 + e] : 0.0f;
+            }
+            lds_sync();
+#pragma unroll
+            for (int u = 0; u < (NB * 64 + MT - 1) / MT; ++u) {
+                const int i = tid + u * MT, r = i >> 6, e = i & 63;
+                if (i < NB * 64 && r < n) {
+                    float M = -INFINITY;
+#pragma unroll
+                    for (int sidx = 0; sidx < CROSS_SPLITS_MAX; ++sidx) M = fmaxf(M, cm[r * CROSS_SPLITS_MAX + sidx]);
+                    float Lsum = 0.0f, acc = 0.0f;
+#pragma unroll
+                    for (int sidx = 0; sidx < CROSS_SPLITS_MAX; ++sidx) {
+                        const float mm = cm[r * CROSS_SPLITS_MAX + sidx];
+                        const float w = mm > -INFINITY ? expf(mm - M) : 0.0f;
+                        Lsum += w * cl[r * CROSS_SPLITS_MAX + sidx];
+                        acc += w * ov[u][sidx];
+                    }
+                    st_out(out + (long)r * d + h * 64 + e, acc / Lsum);
+                }
+            }
+        }
+}
+
+// ---- cross-attention: workgroup = (head, key split); all rows share each K/V read; the last split of a head
+// to finish combines the partial softmaxes (no waiting: an arrival counter per head) ----
 template <int NB, typename OT>
 __device__ __forceinline__ void cross_attn_phase(const float *q, const bf16_t *kc, const bf16_t *vc, float *part, OT *out,
                                                  unsigned *head_cnt, int n, int H, int d, int n_ctx, int splits, int per,
@@ -589,53 +644,138 @@ __device__ __forceinline__ void cross_attn_phase(const float *q, const bf16_t *k
                 }
             }
         }
-        __syncthreads();  // partial stores acknowledged (vmcnt(0)) before this split is counted
-        if (tid == 0) {
-            const unsigned old = __hip_atomic_fetch_add(&head_cnt[h], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned last = old == (unsigned)splits - 1;
-            if (last) __hip_atomic_store(&head_cnt[h], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
-            *flag = last;
+        cross_count_and_combine<NB, OT>(part, out, head_cnt, sc, flag, n, H, d, h, splits);
+        lds_sync();
+    }
+}
+
+// ---- cross-attention on the matrix cores (splits of at most 128 keys) ----
+// scores  S[row][key] = q[row] . K[key]:  A = q rows as bf16 (LDS), B = K rows straight from global memory (a lane's
+//         16 bytes are 8 consecutive head dims of its key), one 16-key tile per wave, 2 x v_mfma_f32_16x16x32_bf16;
+// P . V   O[row][dim] = sum_key P[row][key] V[key][dim]:  B needs 8 consecutive KEYS of one dim per lane, so the V
+//         tile is transposed on its way into LDS; wave w takes dims 16*(w&3).. and key half w>>2, 2 MFMAs each.
+constexpr int XK = 128;      // keys per split
+constexpr int XLDP = XK + 8; // LDS row stride (elements) of the [*][key] tiles: conflict-free 16-byte reads
+
+template <int NB, typename OT>
+__device__ __forceinline__ void cross_attn_phase_mfma(const float *q, const bf16_t *kc, const bf16_t *vc, float *part, OT *out,
+                                                      unsigned *head_cnt, int n, int H, int d, int n_ctx, int splits, int per,
+                                                      float *lds) {
+    bf16_t *qb = reinterpret_cast<bf16_t *>(lds);  // [16][72]   q rows (rows >= n zero)
+    bf16_t *vt = qb + 16 * 72;                     // [64][XLDP] V transposed: [dim][key]
+    bf16_t *pb = vt + 64 * XLDP;                   // [16][XLDP] probabilities (rows >= n zero)
+    float *sc = reinterpret_cast<float *>(pb + 16 * XLDP);  // [NB][XK] scores; reused by the combine
+    float *red = sc + (NB * XK > 2 * NB * CROSS_SPLITS_MAX ? NB * XK : 2 * NB * CROSS_SPLITS_MAX);  // [8][64][4]
+    float *ml = red + 8 * 64 * 4;                  // [NB][2]
+    unsigned *flag = reinterpret_cast<unsigned *>(ml + NB * 2);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+    // zero the operand tiles once: rows >= n and keys >= nk must contribute nothing
+    for (int i = tid; i < (16 * 72 + 16 * XLDP) / 2; i += MT) {
+        unsigned *z = i < 16 * 72 / 2 ? reinterpret_cast<unsigned *>(qb) + i : reinterpret_cast<unsigned *>(pb) + (i - 16 * 72 / 2);
+        *z = 0u;
+    }
+    for (int it = blockIdx.x; it < H * splits; it += gridDim.x) {
+        const int h = it / splits, sp = it - h * splits;
+        const int j0 = sp * per, nk = min(per, n_ctx - j0);  // may be <= 0 for a trailing split
+        // ---- every global load of the item up front ----
+        float qreg[(NB * 64 + MT - 1) / MT];
+#pragma unroll
+        for (int u = 0; u < (NB * 64 + MT - 1) / MT; ++u) {
+            const int i = tid + u * MT, r = i >> 6, e = i & 63;
+            qreg[u] = (i < NB * 64 && r < n) ? q[(long)r * d + h * 64 + e] : 0.0f;
+        }
+        const int kkey = 16 * wave + fr;  // this lane's key in the score tile of its wave
+        uint4 kb[2];
+        {
+            const bf16_t *kr = kc + (long)(j0 + (kkey < nk ? kkey : 0)) * d + h * 64 + 8 * fq;
+            kb[0] = *reinterpret_cast<const uint4 *>(kr);
+            kb[1] = *reinterpret_cast<const uint4 *>(kr + 32);
+        }
+        const int vk = tid >> 3, e8 = tid & 7;  // V: thread loads 8 dims of keys vk and vk + 64
+        uint4 vq[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int j = vk + 64 * i;
+            vq[i] = j < nk ? *reinterpret_cast<const uint4 *>(vc + (long)(j0 + j) * d + h * 64 + e8 * 8) : make_uint4(0, 0, 0, 0);
+        }
+        // ---- stage q (bf16) and V^T in LDS ----
+#pragma unroll
+        for (int u = 0; u < (NB * 64 + MT - 1) / MT; ++u) {
+            const int i = tid + u * MT;
+            if (i < NB * 64) qb[(i >> 6) * 72 + (i & 63)] = to_bf16(qreg[u]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int j = vk + 64 * i;
+            const unsigned w4[4] = {vq[i].x, vq[i].y, vq[i].z, vq[i].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                vt[(e8 * 8 + 2 * c) * XLDP + j] = (bf16_t)(w4[c] & 0xffffu);
+                vt[(e8 * 8 + 2 * c + 1) * XLDP + j] = (bf16_t)(w4[c] >> 16);
+            }
         }
         lds_sync();
-        if (*flag) {  // every split of head h is in memory: combine in fixed split order, loads first
-            float *cm = sc, *cl = sc + NB * CROSS_SPLITS_MAX;  // split maxima / sums of all rows, staged in LDS
-            for (int i = tid; i < NB * CROSS_SPLITS_MAX; i += MT) {
-                const int r = i / CROSS_SPLITS_MAX, sidx = i - r * CROSS_SPLITS_MAX;
-                const bool on = r < n && sidx < splits;
-                const float *pp = part + (((long)r * H + h) * splits + (on ? sidx : 0)) * CPART;
-                cm[i] = on ? pp[0] : -INFINITY;
-                cl[i] = on ? pp[1] : 0.0f;
+        // ---- scores ----
+        {
+            f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const uint4 af = *reinterpret_cast<const uint4 *>(qb + fr * 72 + 32 * s2 + 8 * fq);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8b, af), __builtin_bit_cast(bf16x8b, kb[s2]), acc, 0,
+                                                              0, 0);
             }
-            float ov[(NB * 64 + MT - 1) / MT][CROSS_SPLITS_MAX];
+            // lane holds rows 4*fq + r of key kkey
 #pragma unroll
-            for (int u = 0; u < (NB * 64 + MT - 1) / MT; ++u) {
-                const int i = tid + u * MT, r = i >> 6, e = i & 63;
-                const bool rowon = i < NB * 64 && r < n;
-                const float *pp = part + ((long)(rowon ? r : 0) * H + h) * splits * CPART;
-#pragma unroll
-                for (int sidx = 0; sidx < CROSS_SPLITS_MAX; ++sidx)
-                    ov[u][sidx] = (rowon && sidx < splits) ? pp[sidx * CPART + 2 + e] : 0.0f;
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * fq + r;
+                if (row < NB) sc[row * XK + kkey] = kkey < nk ? acc[r] : -INFINITY;
             }
-            lds_sync();
+        }
+        lds_sync();
+        // ---- per-row softmax over the split (wave w: row w) ----
+        if (wave < NB) {
+            const int r = wave;
+            const float v0 = sc[r * XK + lane], v1 = sc[r * XK + 64 + lane];
+            const float mx = wave_max_all(fmaxf(v0, v1));
+            const float e0 = lane < nk ? expf(v0 - mx) : 0.0f, e1 = (64 + lane) < nk ? expf(v1 - mx) : 0.0f;
+            const float sum = wave_sum_all(e0 + e1);
+            pb[r * XLDP + lane] = to_bf16(e0);
+            pb[r * XLDP + 64 + lane] = to_bf16(e1);
+            if (lane == 0) {
+                ml[r * 2] = mx;
+                ml[r * 2 + 1] = sum;
+            }
+        }
+        lds_sync();
+        // ---- P . V ----
+        {
+            const int nt = wave & 3, kh = wave >> 2;
+            f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-            for (int u = 0; u < (NB * 64 + MT - 1) / MT; ++u) {
-                const int i = tid + u * MT, r = i >> 6, e = i & 63;
-                if (i < NB * 64 && r < n) {
-                    float M = -INFINITY;
-#pragma unroll
-                    for (int sidx = 0; sidx < CROSS_SPLITS_MAX; ++sidx) M = fmaxf(M, cm[r * CROSS_SPLITS_MAX + sidx]);
-                    float Lsum = 0.0f, acc = 0.0f;
-#pragma unroll
-                    for (int sidx = 0; sidx < CROSS_SPLITS_MAX; ++sidx) {
-                        const float mm = cm[r * CROSS_SPLITS_MAX + sidx];
-                        const float w = mm > -INFINITY ? expf(mm - M) : 0.0f;
-                        Lsum += w * cl[r * CROSS_SPLITS_MAX + sidx];
-                        acc += w * ov[u][sidx];
-                    }
-                    st_out(out + (long)r * d + h * 64 + e, acc / Lsum);
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int ks = 2 * kh + s2;
+                const uint4 af = *reinterpret_cast<const uint4 *>(pb + fr * XLDP + 32 * ks + 8 * fq);
+                const uint4 bfr = *reinterpret_cast<const uint4 *>(vt + (16 * nt + fr) * XLDP + 32 * ks + 8 * fq);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8b, af), __builtin_bit_cast(bf16x8b, bfr), acc, 0, 0,
+                                                              0);
+            }
+            *reinterpret_cast<f32x4 *>(red + (wave * 64 + lane) * 4) = acc;  // rows 4*fq + r, dim 16*nt + fr
+        }
+        lds_sync();
+        for (int i = tid; i < NB * 64; i += MT) {
+            const int r = i >> 6, e = i & 63;
+            if (r < n) {
+                const int nt = e >> 4, src_lane = (r >> 2) * 16 + (e & 15), rr = r & 3;
+                const float v = red[(nt * 64 + src_lane) * 4 + rr] + red[((4 + nt) * 64 + src_lane) * 4 + rr];
+                float *pp = part + (((long)r * H + h) * splits + sp) * CPART;
+                st_agent(pp + 2 + e, v);
+                if (e == 0) {
+                    st_agent(pp, ml[r * 2]);
+                    st_agent(pp + 1, ml[r * 2 + 1]);
                 }
             }
         }
+        cross_count_and_combine<NB, OT>(part, out, head_cnt, sc, flag, n, H, d, h, splits);
         lds_sync();
     }
 }
@@ -768,6 +908,15 @@ __global__ __launch_bounds__(MEGA_THREADS) void proj_wg_kernel(Proj p, const voi
     proj_phase<NB, LN, EPI, 1, J, true>(nullptr, w, p, xin, ln_w, ln_b, n, e, lds);
 }
 
+template <int NB, typename OT>
+__global__ __launch_bounds__(MEGA_THREADS) void cross_attn_mfma_kernel(const float *q, const bf16_t *kc, const bf16_t *vc, float *part,
+                                                                        OT *out, unsigned *head_cnt, int n, int H, int d, int n_ctx,
+                                                                        int splits, int per) {
+    __shared__ __attribute__((aligned(16))) float lds[(16 * 72 + 64 * XLDP + 16 * XLDP) / 2 + NB * XK + 2 * NB * CROSS_SPLITS_MAX +
+                                                      8 * 64 * 4 + NB * 2 + 16];
+    cross_attn_phase_mfma<NB, OT>(q, kc, vc, part, out, head_cnt, n, H, d, n_ctx, splits, per, lds);
+}
+
 }  // namespace
 
 void launch_proj_wg(const GemvArgs &a, hipStream_t st) {
@@ -831,9 +980,17 @@ void launch_cross_attn_wg(const float *q, const void *kc, const void *vc, float 
     const int per = ceil_div(n_ctx, splits);
     MW_CHECK(per <= MEGA_CROSS_PER_MAX, "cross_attn_wg: too many keys per split");
     const dim3 grid(H * splits), block(MT);
-#define MW_CROSS(NBv, OTv) \
-    hipLaunchKernelGGL((cross_attn_wg_kernel<NBv, OTv>), grid, block, 0, st, q, (const bf16_t *)kc, (const bf16_t *)vc, partial, (OTv *)out, \
-                       head_cnt, n, H, d, n_ctx, splits, per)
+    static const bool no_mfma = getenv("MI355_WHISPER_NO_CROSS_MFMA") != nullptr;
+    const bool mfma = per <= XK && !no_mfma;  // matrix-core variant for splits of at most 128 keys
+#define MW_CROSS(NBv, OTv)                                                                                                          \
+    do {                                                                                                                            \
+        if (mfma)                                                                                                                   \
+            hipLaunchKernelGGL((cross_attn_mfma_kernel<NBv, OTv>), grid, block, 0, st, q, (const bf16_t *)kc, (const bf16_t *)vc,   \
+                               partial, (OTv *)out, head_cnt, n, H, d, n_ctx, splits, per);                                        \
+        else                                                                                                                        \
+            hipLaunchKernelGGL((cross_attn_wg_kernel<NBv, OTv>), grid, block, 0, st, q, (const bf16_t *)kc, (const bf16_t *)vc,     \
+                               partial, (OTv *)out, head_cnt, n, H, d, n_ctx, splits, per);                                        \
+    } while (0)
     if (out_t == DType::F32) {
         if (n == 1) MW_CROSS(1, float);
         else MW_CROSS(5, float);
