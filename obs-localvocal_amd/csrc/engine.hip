@@ -111,7 +111,7 @@ std::unique_ptr<Context> create_context(const unsigned char *data, size_t size, 
     dev_alloc_bytes(c->d_ffd, TC * 4 * d * 4);
     dev_alloc(c->d_part, TC * H * CROSS_SPLITS_MAX * 66);
     dev_alloc(c->d_logits, (size_t)LOGIT_ROWS * nv);
-    dev_alloc(c->d_work, (size_t)LOGIT_ROWS * nv);
+    dev_alloc(c->d_work, process_logits_work_floats(LOGIT_ROWS, nv));
     dev_alloc(c->d_suppress, nv);
     dev_alloc(c->d_row_state, LOGIT_ROWS);
     dev_alloc(c->d_row_res, LOGIT_ROWS);

@@ -228,6 +228,8 @@ struct LogitsRowResult {
     float p[MAX_CAND], plog[MAX_CAND];
 };
 // suppress: per-token byte mask (1 = always suppressed).  Optional full-row dumps for parity tests.
+// work: process_logits_work_floats(max rows, n_vocab) floats (slab records + the masked rows).
+size_t process_logits_work_floats(int n_rows_max, int n_vocab);
 void launch_process_logits(const float *logits, long ld, const unsigned char *suppress, const LogitsParams &p,
                            const LogitsRowState *d_rows, LogitsRowResult *d_res, int n_rows, float *work,
                            float *dump_logits, float *dump_logprobs, float *dump_probs, hipStream_t st);
