@@ -354,6 +354,122 @@ __device__ __forceinline__ void proj_phase(unsigned long long *stamp, WRegs<TPB,
     if (stamp && tid == 0) stamp[3] = wall_clock64();
 }
 
+// ---- the LayerNorm-fused projection as a kernel of its own: one 16-feature tile per workgroup, K <= 1280 ----
+// Same arithmetic as proj_phase<LN>, written so that the compiler emits straight-line code: every global load
+// is unconditional (clamped address, value selected afterwards) and issued before the first wait.  A load
+// under a predicate becomes a branch with `s_waitcnt vmcnt(0)` at its join; in proj_phase that put the weight
+// loads first and then five serialised (row, gamma, beta) round trips in front of the LayerNorm — 3 to 4 us
+// of a 5 us kernel (tools/microbench/mb_phases).
+template <int EPI>
+__device__ __forceinline__ void proj_finish(float v, int erow, int n_e, const Proj &p, const Epi &e, float res_e) {
+    if constexpr (EPI == EPI_QKV) {
+        const int d = e.d;
+        if (n_e < d) {
+            st_agent(e.q + (long)erow * d + n_e, v * e.qk_scale);
+        } else {
+            const long off = ((long)e.slot[erow] * e.TC + e.pos[erow]) * d;
+            if (n_e < 2 * d) st_agent(e.kc + off + (n_e - d), to_bf16(v * e.qk_scale));
+            else st_agent(e.vc + off + (n_e - 2 * d), to_bf16(v));
+        }
+    } else if constexpr (EPI == EPI_RES) {
+        st_agent(e.xout + (long)erow * p.N + n_e, v + res_e);
+    } else if constexpr (EPI == EPI_SCALE) {
+        st_agent(e.fout + (long)erow * p.N + n_e, v * e.scale);
+    } else if constexpr (EPI == EPI_GELU_BF16) {
+        st_agent(e.hout + (long)erow * e.ldo + n_e, to_bf16(gelu_f(v)));
+    } else {
+        st_agent(e.fout + (long)erow * e.ldo + n_e, gelu_f(v));
+    }
+}
+
+template <int NB, int EPI>
+__device__ __forceinline__ void proj_ln_tile(const Proj &p, const float *xin, const float *ln_w, const float *ln_b, int n, const Epi &e,
+                                             bf16_t *xs, float *red, unsigned long long *stamp) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+    const int K = p.K, nf4 = K >> 2, ksteps = K >> 5, ldxs = K + 8, tile = blockIdx.x;
+    // ---- every global load of the kernel, in the order their values are needed ----
+    const int row = wave < n ? wave : n - 1;  // waves beyond the rows recompute the last row (and do not store it)
+    const float *xr = xin + (long)row * K;
+    float4 v[LN_MAX_F4], gw[LN_MAX_F4], gb[LN_MAX_F4];
+#pragma unroll
+    for (int i = 0; i < LN_MAX_F4; ++i) v[i] = *reinterpret_cast<const float4 *>(xr + 4 * min(lane + 64 * i, nf4 - 1));
+#pragma unroll
+    for (int i = 0; i < LN_MAX_F4; ++i) {
+        const int c = min(lane + 64 * i, nf4 - 1);
+        gw[i] = *reinterpret_cast<const float4 *>(ln_w + 4 * c);
+        gb[i] = *reinterpret_cast<const float4 *>(ln_b + 4 * c);
+    }
+    uint4 w[5];
+    {
+        const bf16_t *wrow = p.W + (long)(tile * 16 + fr) * K + 8 * fq;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) w[j] = ld_stream16(wrow + 32 * min(wave + 8 * j, ksteps - 1));
+    }
+    const int el = (tid & 255) >> 2, er = tid & 3, erow = 4 * (el >> 4) + er, n_e = tile * 16 + (el & 15);
+    const float bias_e = p.bias ? p.bias[n_e] : 0.0f;
+    long kv_off = 0;
+    if constexpr (EPI == EPI_QKV) {
+        const int rr = erow < n ? erow : 0;
+        kv_off = ((long)e.slot[rr] * e.TC + e.pos[rr]) * e.d;
+    }
+    // ---- LayerNorm of the wave's row (wave reductions only) -> bf16 in LDS ----
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_F4; ++i) s += lane + 64 * i < nf4 ? (v[i].x + v[i].y) + (v[i].z + v[i].w) : 0.0f;
+    const float mean = wave_total(s) * (1.0f / (float)K);
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_F4; ++i) {
+        const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
+        q += lane + 64 * i < nf4 ? (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3) : 0.0f;
+    }
+    const float rstd = rsqrtf(wave_total(q) * (1.0f / (float)K) + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < LN_MAX_F4; ++i) {
+        const int c = lane + 64 * i;
+        const float y0 = (v[i].x - mean) * rstd * gw[i].x + gb[i].x, y1 = (v[i].y - mean) * rstd * gw[i].y + gb[i].y;
+        const float y2 = (v[i].z - mean) * rstd * gw[i].z + gb[i].z, y3 = (v[i].w - mean) * rstd * gw[i].w + gb[i].w;
+        uint2 pk;
+        pk.x = (unsigned)to_bf16(y0) | ((unsigned)to_bf16(y1) << 16);
+        pk.y = (unsigned)to_bf16(y2) | ((unsigned)to_bf16(y3) << 16);
+        if (c < nf4 && wave < n) *reinterpret_cast<uint2 *>(xs + wave * ldxs + 4 * c) = pk;
+    }
+    if (stamp && tid == 0) stamp[0] = wall_clock64();
+    lds_sync();
+    if (stamp && tid == 0) stamp[1] = wall_clock64();
+    // ---- matrix-core products ----
+    {
+        const bf16_t *arow = xs + (fr < n ? fr : 0) * ldxs + 8 * fq;  // rows >= n: any valid row, result ignored
+        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int step = wave + 8 * j;
+            const uint4 af = *reinterpret_cast<const uint4 *>(arow + 32 * min(step, ksteps - 1));
+            const uint4 wv = step < ksteps ? w[j] : make_uint4(0, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8b, af), __builtin_bit_cast(bf16x8b, wv), acc, 0, 0, 0);
+        }
+        *reinterpret_cast<f32x4 *>(red + (wave * 64 + lane) * 4) = acc;
+    }
+    lds_sync();
+    if (stamp && tid == 0) stamp[2] = wall_clock64();
+    // ---- finish: fixed-order sum of the 8 partial tiles, bias, epilogue ----
+    if (tid < 256 && erow < n) {
+        float r = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r += red[(k * 64 + el) * 4 + er];
+        r += bias_e;
+        if constexpr (EPI == EPI_QKV) {
+            const int d = e.d;
+            if (n_e < d) st_agent(e.q + (long)erow * d + n_e, r * e.qk_scale);
+            else if (n_e < 2 * d) st_agent(e.kc + kv_off + (n_e - d), to_bf16(r * e.qk_scale));
+            else st_agent(e.vc + kv_off + (n_e - 2 * d), to_bf16(r));
+        } else {
+            proj_finish<EPI>(r, erow, n_e, p, e, 0.0f);
+        }
+    }
+    if (stamp && tid == 0) stamp[3] = wall_clock64();
+}
+
 // ---- self-attention over the indirected KV cache: one workgroup per (row, head), thread = key.  Every
 // global load of the phase (index table, K row, the thread's V chunks) is issued before anything waits. ----
 __device__ __forceinline__ void st_out(bf16_t *p, float v) { st_agent(p, to_bf16(v)); }
@@ -908,6 +1024,14 @@ __global__ __launch_bounds__(MEGA_THREADS) void proj_wg_kernel(Proj p, const voi
     proj_phase<NB, LN, EPI, 1, J, true>(nullptr, w, p, xin, ln_w, ln_b, n, e, lds);
 }
 
+template <int NB, int EPI>
+__global__ __launch_bounds__(MEGA_THREADS) void proj_ln_tile_kernel(Proj p, const float *xin, const float *ln_w, const float *ln_b, int n,
+                                                                     Epi e) {
+    __shared__ __attribute__((aligned(16))) bf16_t xs[NB * (256 * LN_MAX_F4 + 8)];
+    __shared__ __attribute__((aligned(16))) float red[8 * 64 * 4];
+    proj_ln_tile<NB, EPI>(p, xin, ln_w, ln_b, n, e, xs, red, nullptr);
+}
+
 template <int NB, typename OT>
 __global__ __launch_bounds__(MEGA_THREADS) void cross_attn_mfma_kernel(const float *q, const bf16_t *kc, const bf16_t *vc, float *part,
                                                                         OT *out, unsigned *head_cnt, int n, int H, int d, int n_ctx,
@@ -930,33 +1054,42 @@ void launch_proj_wg(const GemvArgs &a, hipStream_t st) {
     const dim3 grid(a.N / 16), block(MT);
 #define MW_PROJ(NBv, LNv, EPIv, Jv) \
     hipLaunchKernelGGL((proj_wg_kernel<NBv, LNv, EPIv, Jv>), grid, block, 0, st, p, (const void *)a.x, a.ln_w, a.ln_b, a.n, e)
-#define MW_PROJ_NB(LNv, EPIv, Jv) \
-    do {                           \
-        if (a.n == 1) MW_PROJ(1, LNv, EPIv, Jv); \
-        else MW_PROJ(5, LNv, EPIv, Jv);          \
+#define MW_PROJ_LN(NBv, EPIv) \
+    hipLaunchKernelGGL((proj_ln_tile_kernel<NBv, EPIv>), grid, block, 0, st, p, (const float *)a.x, a.ln_w, a.ln_b, a.n, e)
+#define MW_PROJ_NB(LNv, EPIv, Jv)                \
+    do {                                          \
+        if (a.n == 1) MW_PROJ(1, LNv, EPIv, Jv);  \
+        else MW_PROJ(5, LNv, EPIv, Jv);           \
+    } while (0)
+#define MW_PROJ_LN_NB(EPIv)               \
+    do {                                   \
+        if (a.n == 1) MW_PROJ_LN(1, EPIv); \
+        else MW_PROJ_LN(5, EPIv);          \
     } while (0)
     if (a.qkv) {
         MW_CHECK(ln && a.ln_b && spw <= 5 && a.K <= 256 * LN_MAX_F4 && a.N == 3 * a.K && a.ldo == a.K && a.kv_t == DType::BF16,
                  "proj_wg: qkv class");
         e.q = a.out; e.kc = (bf16_t *)a.kcache; e.vc = (bf16_t *)a.vcache; e.slot = a.d_slot; e.pos = a.d_pos; e.TC = a.n_text_ctx;
         e.d = a.K; e.qk_scale = a.qk_scale;
-        MW_PROJ_NB(true, EPI_QKV, 5);
+        MW_PROJ_LN_NB(EPI_QKV);
     } else if (ln && a.act == ACT_GELU) {
         MW_CHECK(a.ln_b && spw <= 5 && a.K <= 256 * LN_MAX_F4 && !a.R, "proj_wg: fc1 class");
         e.hout = (bf16_t *)a.out; e.fout = a.out; e.ldo = (int)a.ldo;
-        if (a.out_bf16) MW_PROJ_NB(true, EPI_GELU_BF16, 5);
-        else MW_PROJ_NB(true, EPI_GELU_F32, 5);
+        if (a.out_bf16) MW_PROJ_LN_NB(EPI_GELU_BF16);
+        else MW_PROJ_LN_NB(EPI_GELU_F32);
     } else if (ln) {
         MW_CHECK(a.ln_b && spw <= 5 && a.K <= 256 * LN_MAX_F4 && !a.R && a.ldo == a.N && a.act == ACT_NONE, "proj_wg: cross-q class");
         e.fout = a.out; e.scale = a.out_scale;
-        MW_PROJ_NB(true, EPI_SCALE, 5);
+        MW_PROJ_LN_NB(EPI_SCALE);
     } else {
         MW_CHECK(a.x_bf16 && a.R && a.ldo == a.N && a.act == ACT_NONE && a.out_scale == 1.0f && spw <= 20, "proj_wg: residual class");
         e.res = a.R; e.xout = a.out;
         if (spw <= 5) MW_PROJ_NB(false, EPI_RES, 5);
         else MW_PROJ_NB(false, EPI_RES, 20);
     }
+#undef MW_PROJ_LN_NB
 #undef MW_PROJ_NB
+#undef MW_PROJ_LN
 #undef MW_PROJ
     MW_HIP(hipGetLastError());
 }
