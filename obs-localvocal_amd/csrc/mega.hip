@@ -382,28 +382,35 @@ __device__ __forceinline__ void proj_finish(float v, int erow, int n_e, const Pr
     }
 }
 
+// The tile's weights (16 rows of K bf16, contiguous in memory) are loaded fully coalesced — wave w takes rows
+// 2w and 2w+1 as consecutive 1 KB pieces — and re-read from LDS in the MFMA B-fragment layout.  Loading the
+// fragments straight from global memory touches 64 cache lines per instruction (16 bytes of each) instead of
+// 8 and was 1.3-1.4 us slower per launch (tools/microbench/mb_latency, "B-fragment pattern").
 template <int NB, int EPI>
 __device__ __forceinline__ void proj_ln_tile(const Proj &p, const float *xin, const float *ln_w, const float *ln_b, int n, const Epi &e,
-                                             bf16_t *xs, float *red, unsigned long long *stamp) {
+                                             bf16_t *xs, bf16_t *wt, float *red, unsigned long long *stamp) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
     const int K = p.K, nf4 = K >> 2, ksteps = K >> 5, ldxs = K + 8, tile = blockIdx.x;
     // ---- every global load of the kernel, in the order their values are needed ----
-    const int row = wave < n ? wave : n - 1;  // waves beyond the rows recompute the last row (and do not store it)
-    const float *xr = xin + (long)row * K;
+    // (a wave without a row issues the same loads with every lane on one address: a single cache-line request each,
+    // still straight-line code — a branch around the loads made the compiler wait for them inside the branch)
+    const bool has_row = wave < n;
+    const float *xr = xin + (long)(has_row ? wave : 0) * K;
     float4 v[LN_MAX_F4], gw[LN_MAX_F4], gb[LN_MAX_F4];
 #pragma unroll
-    for (int i = 0; i < LN_MAX_F4; ++i) v[i] = *reinterpret_cast<const float4 *>(xr + 4 * min(lane + 64 * i, nf4 - 1));
+    for (int i = 0; i < LN_MAX_F4; ++i) v[i] = *reinterpret_cast<const float4 *>(xr + (has_row ? 4 * min(lane + 64 * i, nf4 - 1) : 0));
 #pragma unroll
     for (int i = 0; i < LN_MAX_F4; ++i) {
-        const int c = min(lane + 64 * i, nf4 - 1);
-        gw[i] = *reinterpret_cast<const float4 *>(ln_w + 4 * c);
-        gb[i] = *reinterpret_cast<const float4 *>(ln_b + 4 * c);
+        const int c = has_row ? 4 * min(lane + 64 * i, nf4 - 1) : 0;
+        gw[i] = *reinterpret_cast<const float4 *>(ln_w + c);
+        gb[i] = *reinterpret_cast<const float4 *>(ln_b + c);
     }
     uint4 w[5];
+    const int wpieces = K >> 2;  // 16-byte pieces in the wave's two rows
     {
-        const bf16_t *wrow = p.W + (long)(tile * 16 + fr) * K + 8 * fq;
+        const bf16_t *wbase = p.W + (long)(tile * 16 + 2 * wave) * K;
 #pragma unroll
-        for (int j = 0; j < 5; ++j) w[j] = ld_stream16(wrow + 32 * min(wave + 8 * j, ksteps - 1));
+        for (int j = 0; j < 5; ++j) w[j] = ld_stream16(wbase + 8 * min(lane + 64 * j, wpieces - 1));
     }
     const int el = (tid & 255) >> 2, er = tid & 3, erow = 4 * (el >> 4) + er, n_e = tile * 16 + (el & 15);
     const float bias_e = p.bias ? p.bias[n_e] : 0.0f;
@@ -435,17 +442,26 @@ __device__ __forceinline__ void proj_ln_tile(const Proj &p, const float *xin, co
         if (c < nf4 && wave < n) *reinterpret_cast<uint2 *>(xs + wave * ldxs + 4 * c) = pk;
     }
     if (stamp && tid == 0) stamp[0] = wall_clock64();
+    // ---- the wave's two weight rows -> LDS ----
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int pc = lane + 64 * j, half = K >> 3;  // pieces per row
+        const int r = pc >= half ? 1 : 0;
+        if (pc < wpieces) *reinterpret_cast<uint4 *>(wt + (2 * wave + r) * ldxs + 8 * (pc - r * half)) = w[j];
+    }
     lds_sync();
     if (stamp && tid == 0) stamp[1] = wall_clock64();
     // ---- matrix-core products ----
     {
         const bf16_t *arow = xs + (fr < n ? fr : 0) * ldxs + 8 * fq;  // rows >= n: any valid row, result ignored
+        const bf16_t *brow = wt + fr * ldxs + 8 * fq;
         f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
-            const int step = wave + 8 * j;
-            const uint4 af = *reinterpret_cast<const uint4 *>(arow + 32 * min(step, ksteps - 1));
-            const uint4 wv = step < ksteps ? w[j] : make_uint4(0, 0, 0, 0);
+            const int step = wave + 8 * j, sc = min(step, ksteps - 1);
+            const uint4 af = *reinterpret_cast<const uint4 *>(arow + 32 * sc);
+            uint4 wv = *reinterpret_cast<const uint4 *>(brow + 32 * sc);
+            if (step >= ksteps) wv = make_uint4(0, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8b, af), __builtin_bit_cast(bf16x8b, wv), acc, 0, 0, 0);
         }
         *reinterpret_cast<f32x4 *>(red + (wave * 64 + lane) * 4) = acc;
@@ -1028,8 +1044,9 @@ template <int NB, int EPI>
 __global__ __launch_bounds__(MEGA_THREADS) void proj_ln_tile_kernel(Proj p, const float *xin, const float *ln_w, const float *ln_b, int n,
                                                                      Epi e) {
     __shared__ __attribute__((aligned(16))) bf16_t xs[NB * (256 * LN_MAX_F4 + 8)];
+    __shared__ __attribute__((aligned(16))) bf16_t wt[16 * (256 * LN_MAX_F4 + 8)];
     __shared__ __attribute__((aligned(16))) float red[8 * 64 * 4];
-    proj_ln_tile<NB, EPI>(p, xin, ln_w, ln_b, n, e, xs, red, nullptr);
+    proj_ln_tile<NB, EPI>(p, xin, ln_w, ln_b, n, e, xs, wt, red, nullptr);
 }
 
 template <int NB, typename OT>

@@ -15,6 +15,7 @@ __global__ void producer(float *x, int cnt, float v) {
     if (i < cnt) x[i] = v + 0.001f * (float)(i % 97);
 }
 
+// MODE 4: weights only, in the MFMA B-fragment pattern (lane -> row l&15, 16 bytes at k = 32*step + 8*(l>>4))
 // MODE 0: x only; 1: weights only; 2: x then weights (x consumed first); 3: weights issued first, then x
 template <int MODE, int J>
 __global__ __launch_bounds__(512) void probe(const float *x, int xcnt, const unsigned short *W, long wg_elems, float *sink,
@@ -34,6 +35,12 @@ __global__ __launch_bounds__(512) void probe(const float *x, int xcnt, const uns
         asm volatile("" : "+v"(acc));
         __syncthreads();
         t1 = wall_clock64();
+    }
+    if constexpr (MODE == 4) {
+        const int lane = tid & 63, wave = tid >> 6, K = J * 256;
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+            w[j] = __builtin_nontemporal_load((const u32x4 *)(wb + (long)(lane & 15) * K + 32 * (wave + 8 * j) + 8 * (lane >> 4)));
     }
     if constexpr (MODE == 1 || MODE == 2) {
 #pragma unroll
@@ -109,6 +116,8 @@ int main() {
         run<0, 5>("x only, x untouched since long ago", wgs, false, st, x, xcnt, W, wtotal, sink, stamps);
         run<1, 5>("weights only (5 x 16 B per lane, cold)", wgs, true, st, x, xcnt, W, wtotal, sink, stamps);
         run<1, 20>("weights only (20 x 16 B per lane, cold)", wgs, true, st, x, xcnt, W, wtotal, sink, stamps);
+        run<4, 5>("weights only, B-fragment pattern (5 per lane, cold)", wgs, true, st, x, xcnt, W, wtotal, sink, stamps);
+        run<4, 5>("weights only, B-fragment pattern, same 105 MB", wgs, true, st, x, xcnt, W, (size_t)wgs * 5 * 512 * 8 * (wgs == 80 ? 16 : 4), sink, stamps);
         run<2, 5>("x consumed, then 5 weight loads", wgs, true, st, x, xcnt, W, wtotal, sink, stamps);
         run<3, 5>("5 weight loads issued, then x", wgs, true, st, x, xcnt, W, wtotal, sink, stamps);
         run<3, 20>("20 weight loads issued, then x", wgs, true, st, x, xcnt, W, wtotal, sink, stamps);

@@ -33,10 +33,11 @@ template <int NB, int EPI>
 __global__ __launch_bounds__(MEGA_THREADS) void proj_probe_ln(Proj p, const void *xin, const float *ln_w, const float *ln_b, int n, Epi e,
                                                               unsigned long long *stamps) {
     __shared__ __attribute__((aligned(16))) bf16_t xs[NB * (256 * LN_MAX_F4 + 8)];
+    __shared__ __attribute__((aligned(16))) bf16_t wt[16 * (256 * LN_MAX_F4 + 8)];
     __shared__ __attribute__((aligned(16))) float red[8 * 64 * 4];
     unsigned long long *s = stamps + (size_t)blockIdx.x * NST;
     if (threadIdx.x == 0) s[4] = wall_clock64();
-    proj_ln_tile<NB, EPI>(p, (const float *)xin, ln_w, ln_b, n, e, xs, red, s);
+    proj_ln_tile<NB, EPI>(p, (const float *)xin, ln_w, ln_b, n, e, xs, wt, red, s);
     __syncthreads();
     if (threadIdx.x == 0) s[5] = wall_clock64();
 }
