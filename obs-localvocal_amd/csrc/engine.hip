@@ -130,6 +130,8 @@ std::unique_ptr<Context> create_context(const unsigned char *data, size_t size, 
         MW_HIP(hipMemsetAsync(c->d_head_cnt, 0, 64 * sizeof(unsigned), c->st));
         c->wg_attn = true;
         c->proj_wg = hp.n_text_state % 128 == 0 && hp.n_text_state <= 1280 && !c->mfma_proj && getenv("MI355_WHISPER_NO_PROJ_WG") == nullptr;
+        // residual classes (attention outputs, fc2) on matrix-core tiles too: K = 8 waves x {1,4} chunks x 2..5 steps x 32
+        c->res_tile = c->proj_wg && hp.n_text_state % 256 == 0 && hp.n_text_state >= 512 && getenv("MI355_WHISPER_NO_RES_TILE") == nullptr;
     }
     // Measured slower than the graph-replayed step (cross-XCD hand-offs cost as much as a launch), so the
     // persistent kernel is an opt-in experiment: MI355_WHISPER_MEGA=1
@@ -364,7 +366,8 @@ void decode(Context &c, const int *tokens, const int *pos, const int *slot, int 
     }
     for (int i = 0; i < n_logit_rows; ++i) MW_CHECK(logit_rows[i] >= 0 && logit_rows[i] < n, "decode: bad logits row");
     hipStream_t st = c.st;
-    const bool mf = c.mfma_proj;  // bf16 rows between attention / MLP kernels and the projections
+    const bool res_tile = c.res_tile && n <= 5;
+    const bool mf = c.mfma_proj || res_tile;  // bf16 rows between attention / MLP kernels and the projections
     const DType act_t = mf ? DType::BF16 : DType::F32;
     const double t0 = now_ms();
     // the pinned staging block may still be read by the previous call's copies
@@ -392,8 +395,8 @@ void decode(Context &c, const int *tokens, const int *pos, const int *slot, int 
             // LayerNorm-fused classes (qkv, cross-q, fc1) at <= 5 rows: one 16-feature tile per workgroup on the
             // matrix cores, LayerNorm per wave (mega.hip); the residual classes stay on the VALU stream kernels,
             // which spread their weight rows over 4x more workgroups (profiles/r01_*)
-            if (c.proj_wg && n <= 5 && g.ln_w && g.tag != GEMV_LOGITS) launch_proj_wg(g, st);
-            else if (mf && g.tag != GEMV_LOGITS) launch_gemv_mfma(g, st);  // matrix-core variant (dec_mfma.hip), opt-in
+            if (c.proj_wg && n <= 5 && (g.ln_w || res_tile) && g.tag != GEMV_LOGITS) launch_proj_wg(g, st);
+            else if (c.mfma_proj && g.tag != GEMV_LOGITS) launch_gemv_mfma(g, st);  // matrix-core variant (dec_mfma.hip), opt-in
             else launch_gemv(g, wt, st);      // VALU weight-streaming path (dec.hip)
             if (prof) MW_HIP(hipEventRecord(c.prof_ev[c.prof_n++], st));
         };

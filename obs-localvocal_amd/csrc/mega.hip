@@ -151,6 +151,7 @@ using WRegsC = WRegs<1, 20>;  // fc2               (K = 4d <= 5120)
 
 using bf16x8b = __attribute__((ext_vector_type(8))) __bf16;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using u32x4v = __attribute__((ext_vector_type(4))) unsigned;
 
 // tiles of a projection owned by this workgroup: first, first + gridDim.x, ...
 struct TileGeo {
@@ -482,6 +483,75 @@ __device__ __forceinline__ void proj_ln_tile(const Proj &p, const float *xin, co
         } else {
             proj_finish<EPI>(r, erow, n_e, p, e, 0.0f);
         }
+    }
+    if (stamp && tid == 0) stamp[3] = wall_clock64();
+}
+
+// ---- residual-class projection (attention outputs, fc2) as a kernel of its own: x rows are bf16, no LayerNorm ----
+// One 16-feature tile per workgroup; wave w owns the k-range [w*K/8, (w+1)*K/8) of all 16 weight rows and of the
+// x rows, in CH chunks of SPC MFMA steps.  Every load is issued up front, coalesced (a row segment of a chunk is
+// 64*SPC contiguous bytes); each chunk is transposed into the fragment layout through a wave-private LDS tile
+// (LDS operations of one wave execute in order: no barrier), so the only workgroup barrier is the one before
+// the 8 partial tiles are summed.
+template <int NB, int SPC, int CH>
+__device__ __forceinline__ void proj_res_tile(const Proj &p, const bf16_t *xin, int n, const Epi &e, bf16_t *lds_t, float *red,
+                                              unsigned long long *stamp) {
+    constexpr int KC = 32 * SPC, LDT = KC + 8, PPR = 4 * SPC;  // k per chunk, LDS row stride, 16-byte pieces per row segment
+    constexpr int XLD = CH * KC + 8, XPR = PPR * CH;           // the wave's x tile: row stride, pieces per row
+    constexpr int XI = (NB * XPR + 63) / 64;                   // x load instructions
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+    const int K = p.K, tile = blockIdx.x, kw = wave * CH * KC;
+    u32x4v xv[XI];  // first-class vectors: as HIP uint4 structs this array was not split into registers and went through
+                    // LDS scratch, whose indexing reads the workgroup size from the dispatch packet in host memory (2-6 us)
+    uint4 w[CH][SPC];
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+        const int pc = min(lane + 64 * i, NB * XPR - 1);
+        xv[i] = *reinterpret_cast<const u32x4v *>(xin + (long)min(pc / XPR, n - 1) * K + kw + 8 * (pc % XPR));
+    }
+    const int el = (tid & 255) >> 2, er = tid & 3, erow = 4 * (el >> 4) + er, n_e = tile * 16 + (el & 15);
+    const float res_e = e.res[(long)(erow < n ? erow : 0) * p.N + n_e];
+    const float bias_v = (p.bias ? p.bias : e.res)[n_e];  // unconditional load: a branch here would split the load block
+    const float bias_e = p.bias ? bias_v : 0.0f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int j = 0; j < SPC; ++j) {
+            const int pc = lane + 64 * j;
+            w[c][j] = ld_stream16(p.W + (long)(tile * 16 + pc / PPR) * K + kw + c * KC + 8 * (pc % PPR));
+        }
+    __builtin_amdgcn_sched_barrier(0);  // every load above is issued before anything below (no sinking next to the use)
+    bf16_t *wt = lds_t + wave * (16 * LDT + NB * XLD), *xt = wt + 16 * LDT;
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+        const int pc = min(lane + 64 * i, NB * XPR - 1);  // surplus lanes rewrite the last piece (same data): no predicate
+        *reinterpret_cast<u32x4v *>(xt + (pc / XPR) * XLD + 8 * (pc % XPR)) = xv[i];
+    }
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (stamp && tid == 0) stamp[0] = wall_clock64();
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+#pragma unroll
+        for (int j = 0; j < SPC; ++j) {
+            const int pc = lane + 64 * j;
+            *reinterpret_cast<uint4 *>(wt + (pc / PPR) * LDT + 8 * (pc % PPR)) = w[c][j];
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < SPC; ++s2) {
+            const uint4 af = *reinterpret_cast<const uint4 *>(xt + (fr < n ? fr : 0) * XLD + c * KC + 32 * s2 + 8 * fq);
+            const uint4 bfr = *reinterpret_cast<const uint4 *>(wt + fr * LDT + 32 * s2 + 8 * fq);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8b, af), __builtin_bit_cast(bf16x8b, bfr), acc, 0, 0, 0);
+        }
+    }
+    if (stamp && tid == 0) stamp[1] = wall_clock64();
+    *reinterpret_cast<f32x4 *>(red + (wave * 64 + lane) * 4) = acc;
+    lds_sync();
+    if (stamp && tid == 0) stamp[2] = wall_clock64();
+    if (tid < 256 && erow < n) {
+        float r = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r += red[(k * 64 + el) * 4 + er];
+        st_agent(e.xout + (long)erow * p.N + n_e, r + bias_e + res_e);
     }
     if (stamp && tid == 0) stamp[3] = wall_clock64();
 }
@@ -1049,6 +1119,13 @@ __global__ __launch_bounds__(MEGA_THREADS) void proj_ln_tile_kernel(Proj p, cons
     proj_ln_tile<NB, EPI>(p, xin, ln_w, ln_b, n, e, xs, wt, red, nullptr);
 }
 
+template <int NB, int SPC, int CH>
+__global__ __launch_bounds__(MEGA_THREADS) void proj_res_tile_kernel(Proj p, const bf16_t *xin, int n, Epi e) {
+    __shared__ __attribute__((aligned(16))) bf16_t lds_t[8 * (16 * (32 * SPC + 8) + NB * (CH * 32 * SPC + 8))];
+    __shared__ __attribute__((aligned(16))) float red[8 * 64 * 4];
+    proj_res_tile<NB, SPC, CH>(p, xin, n, e, lds_t, red, nullptr);
+}
+
 template <int NB, typename OT>
 __global__ __launch_bounds__(MEGA_THREADS) void cross_attn_mfma_kernel(const float *q, const bf16_t *kc, const bf16_t *vc, float *part,
                                                                         OT *out, unsigned *head_cnt, int n, int H, int d, int n_ctx,
@@ -1101,8 +1178,30 @@ void launch_proj_wg(const GemvArgs &a, hipStream_t st) {
     } else {
         MW_CHECK(a.x_bf16 && a.R && a.ldo == a.N && a.act == ACT_NONE && a.out_scale == 1.0f && spw <= 20, "proj_wg: residual class");
         e.res = a.R; e.xout = a.out;
-        if (spw <= 5) MW_PROJ_NB(false, EPI_RES, 5);
-        else MW_PROJ_NB(false, EPI_RES, 20);
+        const int ch = a.K > 1280 ? 4 : 1, spc = a.K / (256 * ch);  // K = 8 waves x CH chunks x SPC steps x 32
+#define MW_RES(NBv, SPCv, CHv) \
+    hipLaunchKernelGGL((proj_res_tile_kernel<NBv, SPCv, CHv>), grid, block, 0, st, p, (const bf16_t *)a.x, a.n, e)
+#define MW_RES_SPC(SPCv)                                    \
+    do {                                                     \
+        if (a.n == 1 && ch == 1) MW_RES(1, SPCv, 1);         \
+        else if (a.n == 1) MW_RES(1, SPCv, 4);               \
+        else if (ch == 1) MW_RES(5, SPCv, 1);                \
+        else MW_RES(5, SPCv, 4);                             \
+    } while (0)
+        if (a.K == 256 * ch * spc && spc >= 2 && spc <= 5) {
+            switch (spc) {
+            case 2: MW_RES_SPC(2); break;
+            case 3: MW_RES_SPC(3); break;
+            case 4: MW_RES_SPC(4); break;
+            default: MW_RES_SPC(5); break;
+            }
+        } else if (spw <= 5) {
+            MW_PROJ_NB(false, EPI_RES, 5);
+        } else {
+            MW_PROJ_NB(false, EPI_RES, 20);
+        }
+#undef MW_RES_SPC
+#undef MW_RES
     }
 #undef MW_PROJ_LN_NB
 #undef MW_PROJ_NB

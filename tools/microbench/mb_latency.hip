@@ -29,7 +29,20 @@ __global__ __launch_bounds__(512) void probe(const float *x, int xcnt, const uns
 #pragma unroll
         for (int j = 0; j < J; ++j) w[j] = __builtin_nontemporal_load((const u32x4 *)(wb + ((long)j * 512 + tid) * 8));
     }
-    if constexpr (MODE != 1) {
+    if constexpr (MODE == 7) {  // x and W (row-segment pattern) issued together; x waited first
+        const int lane = tid & 63, wave = tid >> 6, PPR = 4 * J, K = 8 * 32 * J;
+        const float4 v = *reinterpret_cast<const float4 *>(x + (4 * tid) % xcnt);
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int pc = lane + 64 * j;
+            w[j] = __builtin_nontemporal_load((const u32x4 *)(wb + (long)(pc / PPR) * K + wave * 32 * J + 8 * (pc % PPR)));
+        }
+        acc += v.x + v.y + v.z + v.w;
+        asm volatile("" : "+v"(acc));
+        __syncthreads();
+        t1 = wall_clock64();
+    }
+    if constexpr (MODE != 1 && MODE != 7) {
         const float4 v = *reinterpret_cast<const float4 *>(x + (4 * tid) % xcnt);
         acc += v.x + v.y + v.z + v.w;
         asm volatile("" : "+v"(acc));
@@ -41,6 +54,14 @@ __global__ __launch_bounds__(512) void probe(const float *x, int xcnt, const uns
 #pragma unroll
         for (int j = 0; j < J; ++j)
             w[j] = __builtin_nontemporal_load((const u32x4 *)(wb + (long)(lane & 15) * K + 32 * (wave + 8 * j) + 8 * (lane >> 4)));
+    }
+    if constexpr (MODE == 6) {  // x first (above), then W as 16 rows x (J*64)-byte segments per wave (row stride 8 waves x that)
+        const int lane = tid & 63, wave = tid >> 6, PPR = 4 * J, K = 8 * 32 * J;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int pc = lane + 64 * j;
+            w[j] = __builtin_nontemporal_load((const u32x4 *)(wb + (long)(pc / PPR) * K + wave * 32 * J + 8 * (pc % PPR)));
+        }
     }
     if constexpr (MODE == 1 || MODE == 2) {
 #pragma unroll
@@ -118,6 +139,9 @@ int main() {
         run<1, 20>("weights only (20 x 16 B per lane, cold)", wgs, true, st, x, xcnt, W, wtotal, sink, stamps);
         run<4, 5>("weights only, B-fragment pattern (5 per lane, cold)", wgs, true, st, x, xcnt, W, wtotal, sink, stamps);
         run<4, 5>("weights only, B-fragment pattern, same 105 MB", wgs, true, st, x, xcnt, W, (size_t)wgs * 5 * 512 * 8 * (wgs == 80 ? 16 : 4), sink, stamps);
+        run<7, 5>("x and W (row segments) issued together", wgs, true, st, x, xcnt, W, wtotal, sink, stamps);
+        run<7, 20>("x and 20 W (row segments) issued together", wgs, true, st, x, xcnt, W, wtotal, sink, stamps);
+        run<6, 5>("x, then W as 16 rows x 320 B segments per wave", wgs, true, st, x, xcnt, W, wtotal, sink, stamps);
         run<2, 5>("x consumed, then 5 weight loads", wgs, true, st, x, xcnt, W, wtotal, sink, stamps);
         run<3, 5>("5 weight loads issued, then x", wgs, true, st, x, xcnt, W, wtotal, sink, stamps);
         run<3, 20>("20 weight loads issued, then x", wgs, true, st, x, xcnt, W, wtotal, sink, stamps);

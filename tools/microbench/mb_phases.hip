@@ -21,12 +21,15 @@ template <int NB, bool LN, int EPI, int J>
 __global__ __launch_bounds__(MEGA_THREADS) void proj_probe(Proj p, const void *xin, const float *ln_w, const float *ln_b, int n, Epi e,
                                                            unsigned long long *stamps) {
     __shared__ __attribute__((aligned(16))) float lds[MEGA_XS_BYTES / 4 + 8 * 64 * 4];
-    unsigned long long *s = stamps + (size_t)blockIdx.x * NST;
+    __shared__ unsigned long long s[NST];  // stamps stay in LDS until the end: a global store at entry would be
+                                           // waited for (vmcnt) together with the first loads and distort them
     if (threadIdx.x == 0) s[4] = wall_clock64();
     WRegs<1, J> w;
     proj_phase<NB, LN, EPI, 1, J, true>(s, w, p, xin, ln_w, ln_b, n, e, lds);
     __syncthreads();  // waits for the stores of the whole workgroup
     if (threadIdx.x == 0) s[5] = wall_clock64();
+    if (threadIdx.x == 0)
+        for (int k = 0; k < 6; ++k) stamps[(size_t)blockIdx.x * NST + k] = s[k];
 }
 
 template <int NB, int EPI>
@@ -35,11 +38,28 @@ __global__ __launch_bounds__(MEGA_THREADS) void proj_probe_ln(Proj p, const void
     __shared__ __attribute__((aligned(16))) bf16_t xs[NB * (256 * LN_MAX_F4 + 8)];
     __shared__ __attribute__((aligned(16))) bf16_t wt[16 * (256 * LN_MAX_F4 + 8)];
     __shared__ __attribute__((aligned(16))) float red[8 * 64 * 4];
-    unsigned long long *s = stamps + (size_t)blockIdx.x * NST;
+    __shared__ unsigned long long s[NST];  // stamps stay in LDS until the end: a global store at entry would be
+                                           // waited for (vmcnt) together with the first loads and distort them
     if (threadIdx.x == 0) s[4] = wall_clock64();
     proj_ln_tile<NB, EPI>(p, (const float *)xin, ln_w, ln_b, n, e, xs, wt, red, s);
     __syncthreads();
     if (threadIdx.x == 0) s[5] = wall_clock64();
+    if (threadIdx.x == 0)
+        for (int k = 0; k < 6; ++k) stamps[(size_t)blockIdx.x * NST + k] = s[k];
+}
+
+template <int NB, int SPC, int CH>
+__global__ __launch_bounds__(MEGA_THREADS) void proj_probe_res(Proj p, const bf16_t *xin, int n, Epi e, unsigned long long *stamps) {
+    __shared__ __attribute__((aligned(16))) bf16_t lds_t[8 * (16 * (32 * SPC + 8) + NB * (CH * 32 * SPC + 8))];
+    __shared__ __attribute__((aligned(16))) float red[8 * 64 * 4];
+    __shared__ unsigned long long s[NST];  // stamps stay in LDS until the end: a global store at entry would be
+                                           // waited for (vmcnt) together with the first loads and distort them
+    if (threadIdx.x == 0) s[4] = wall_clock64();
+    proj_res_tile<NB, SPC, CH>(p, xin, n, e, lds_t, red, s);
+    __syncthreads();
+    if (threadIdx.x == 0) s[5] = wall_clock64();
+    if (threadIdx.x == 0)
+        for (int k = 0; k < 6; ++k) stamps[(size_t)blockIdx.x * NST + k] = s[k];
 }
 
 __global__ void producer(float *x, int cnt, float v, unsigned long long *t) {
@@ -49,7 +69,11 @@ __global__ void producer(float *x, int cnt, float v, unsigned long long *t) {
 }
 __global__ void producer_bf16(bf16_t *x, int cnt, unsigned long long *t) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+#ifdef WIDE_PRODUCER
+    if (i < cnt / 8) reinterpret_cast<uint4 *>(x)[i] = make_uint4(0x3c003c01u + i, 0x3c003c01u, 0x3c003c01u, 0x3c003c01u);
+#else
     if (i < cnt) x[i] = (bf16_t)(0x3c00 + (i % 64));
+#endif
     if (i == 0) t[0] = wall_clock64();
 }
 
@@ -91,6 +115,8 @@ int main() {
                  {"fc1  (LN, gelu) N=5120 K=1280", 5120, 1280, true, EPI_GELU_BF16},
                  {"qkv-like (LN, scale) N=3840 K=1280", 3840, 1280, true, EPI_SCALE},
                  {"cq   (LN, scale) N=1280 K=1280", 1280, 1280, true, EPI_SCALE},
+                 {"out lean (res) N=1280 K=1280", 1280, 1280, false, EPI_RES, true},
+                 {"fc2 lean (res) N=1280 K=5120", 1280, 5120, false, EPI_RES, true},
                  {"out  (res) N=1280 K=1280", 1280, 1280, false, EPI_RES},
                  {"fc2  (res) N=1280 K=5120", 1280, 5120, false, EPI_RES}};
     bf16_t *W;
@@ -147,8 +173,16 @@ int main() {
                     hipLaunchKernelGGL((proj_probe<5, true, EPI_SCALE, 5>), dim3(wgs), dim3(MEGA_THREADS), 0, st, p, (const void *)x, lnw, lnb,
                                        n, e, stamps);
             } else {
+#ifdef F32_PRODUCER
+                hipLaunchKernelGGL(producer, dim3((n * c.K / 2 + 255) / 256), dim3(256), 0, st, (float *)xb, n * c.K / 2, (float)it, tprod);
+#else
                 hipLaunchKernelGGL(producer_bf16, dim3((n * c.K + 255) / 256), dim3(256), 0, st, xb, n * c.K, tprod);
-                if (c.K <= 1280)
+#endif
+                if (c.lean && c.K <= 1280)
+                    hipLaunchKernelGGL((proj_probe_res<5, 5, 1>), dim3(wgs), dim3(MEGA_THREADS), 0, st, p, (const bf16_t *)xb, n, e, stamps);
+                else if (c.lean)
+                    hipLaunchKernelGGL((proj_probe_res<5, 5, 4>), dim3(wgs), dim3(MEGA_THREADS), 0, st, p, (const bf16_t *)xb, n, e, stamps);
+                else if (c.K <= 1280)
                     hipLaunchKernelGGL((proj_probe<5, false, EPI_RES, 5>), dim3(wgs), dim3(MEGA_THREADS), 0, st, p, (const void *)xb, nullptr,
                                        nullptr, n, e, stamps);
                 else
