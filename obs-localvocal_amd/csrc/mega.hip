@@ -652,6 +652,90 @@ __device__ __forceinline__ void self_attn_phase(const float *q, const bf16_t *kc
     }
 }
 
+// ---- self-attention as a kernel of its own, straight-line: three dependent load levels and no more ----
+//   1. pos / slot of the row (scalar) and the thread's 8 query values        2. the index-table entries of its keys
+//   3. its 16-byte K and V chunks (thread (jj, e8): keys jj, jj+64, ...; 8 lanes cover a 128-byte head row, so an
+//      instruction reads whole cache lines)
+// Loads beyond the row's length are clamped to its last position (one line for the whole wave) and masked in the
+// arithmetic; nothing is predicated, so the compiler keeps each level's loads in one batch.  Probabilities stay
+// in registers (the thread that scored a key also weights its V chunk).
+template <typename OT>
+__device__ __forceinline__ void self_attn_lean(const float *q, const bf16_t *kc, const bf16_t *vc, const int *slot, const int *pos,
+                                               const int *kv_idx, OT *out, int H, int d, int TC, float *red, float *sm) {
+    constexpr int PVI = MEGA_TC_MAX / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, jj = tid >> 3, e8 = tid & 7;
+    const int r = blockIdx.x / H, h = blockIdx.x - r * H;
+    const int np = pos[r] + 1;
+    const int *idx = kv_idx + (long)slot[r] * TC;
+    const float4 qa = *reinterpret_cast<const float4 *>(q + (long)r * d + h * 64 + e8 * 8);
+    const float4 qb = *reinterpret_cast<const float4 *>(q + (long)r * d + h * 64 + e8 * 8 + 4);
+    int iv[PVI];
+#pragma unroll
+    for (int i = 0; i < PVI; ++i) iv[i] = idx[min(jj + 64 * i, np - 1)];
+    uint4 kq[PVI], vq[PVI];
+#pragma unroll
+    for (int i = 0; i < PVI; ++i) {
+        const long off = ((long)iv[i] * TC + min(jj + 64 * i, np - 1)) * d + h * 64 + e8 * 8;
+        kq[i] = *reinterpret_cast<const uint4 *>(kc + off);
+        vq[i] = *reinterpret_cast<const uint4 *>(vc + off);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // the V loads stay in this batch (the scheduler would sink them next to their use)
+    float sc[PVI], mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < PVI; ++i) {
+        float f[8];
+        unpack8(kq[i], f);
+        float dot = qa.x * f[0];
+        dot = fmaf(qa.y, f[1], dot); dot = fmaf(qa.z, f[2], dot); dot = fmaf(qa.w, f[3], dot);
+        dot = fmaf(qb.x, f[4], dot); dot = fmaf(qb.y, f[5], dot); dot = fmaf(qb.z, f[6], dot); dot = fmaf(qb.w, f[7], dot);
+        dot += __shfl_xor(dot, 1);
+        dot += __shfl_xor(dot, 2);
+        dot += __shfl_xor(dot, 4);
+        sc[i] = jj + 64 * i < np ? dot : -INFINITY;
+        mx = fmaxf(mx, sc[i]);
+    }
+    mx = wave_max_all(mx);
+    if (lane == 0) sm[wave] = mx;
+    lds_sync();
+    mx = sm[0];
+#pragma unroll
+    for (int w = 1; w < MT / 64; ++w) mx = fmaxf(mx, sm[w]);
+    float o[8] = {0, 0, 0, 0, 0, 0, 0, 0}, psum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < PVI; ++i) {
+        const float w = jj + 64 * i < np ? expf(sc[i] - mx) : 0.0f;
+        psum += w;
+        float f[8];
+        unpack8(vq[i], f);
+#pragma unroll
+        for (int q8 = 0; q8 < 8; ++q8) o[q8] = fmaf(w, f[q8], o[q8]);
+    }
+    const float ws = wave_sum_all(e8 == 0 ? psum : 0.0f);  // the 8 lanes of a key hold the same weight: count it once
+#pragma unroll
+    for (int q8 = 0; q8 < 8; ++q8) {
+        float v = o[q8];
+        v += __shfl_xor(v, 8);
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        o[q8] = v;
+    }
+    if (lane == 0) sm[8 + wave] = ws;
+    if ((lane >> 3) == 0) {
+#pragma unroll
+        for (int q8 = 0; q8 < 8; ++q8) red[wave * 64 + e8 * 8 + q8] = o[q8];
+    }
+    lds_sync();
+    if (tid < 64) {
+        float sum = 0.0f, v = 0.0f;
+#pragma unroll
+        for (int w = 0; w < MT / 64; ++w) {
+            sum += sm[8 + w];
+            v += red[w * 64 + tid];
+        }
+        st_out(out + (long)r * d + h * 64 + tid, v / sum);
+    }
+}
+
 constexpr int CPART = 66;
 
 // tail of a cross-attention work item: count this split of head h; the last one to arrive combines the partial
@@ -1093,6 +1177,14 @@ __global__ __launch_bounds__(MEGA_THREADS) void self_attn_wg_kernel(const float 
     self_attn_phase<OT>(q, kc, vc, slot, pos, kv_idx, out, n, H, d, TC, lds);
 }
 
+template <typename OT>
+__global__ __launch_bounds__(MEGA_THREADS) void self_attn_lean_kernel(const float *q, const bf16_t *kc, const bf16_t *vc, const int *slot,
+                                                                       const int *pos, const int *kv_idx, OT *out, int H, int d, int TC) {
+    __shared__ __attribute__((aligned(16))) float red[8 * 64];
+    __shared__ float sm[16];
+    self_attn_lean<OT>(q, kc, vc, slot, pos, kv_idx, out, H, d, TC, red, sm);
+}
+
 template <int NB, typename OT>
 __global__ __launch_bounds__(MEGA_THREADS) void cross_attn_wg_kernel(const float *q, const bf16_t *kc, const bf16_t *vc, float *part,
                                                                       OT *out, unsigned *head_cnt, int n, int H, int d, int n_ctx,
@@ -1214,11 +1306,11 @@ void launch_self_attn_wg(const float *q, const void *kcache, const void *vcache,
                          const int *d_kv_idx, void *out, DType out_t, int n, int H, int d, int n_text_ctx, hipStream_t st) {
     MW_CHECK(n >= 1 && H >= 1 && d == H * 64 && n_text_ctx <= MEGA_TC_MAX, "self_attn_wg: shape");
     if (out_t == DType::F32)
-        hipLaunchKernelGGL(self_attn_wg_kernel<float>, dim3(n * H), dim3(MT), 0, st, q, (const bf16_t *)kcache, (const bf16_t *)vcache,
-                           d_slot, d_pos, d_kv_idx, (float *)out, n, H, d, n_text_ctx);
+        hipLaunchKernelGGL(self_attn_lean_kernel<float>, dim3(n * H), dim3(MT), 0, st, q, (const bf16_t *)kcache, (const bf16_t *)vcache,
+                           d_slot, d_pos, d_kv_idx, (float *)out, H, d, n_text_ctx);
     else
-        hipLaunchKernelGGL(self_attn_wg_kernel<bf16_t>, dim3(n * H), dim3(MT), 0, st, q, (const bf16_t *)kcache, (const bf16_t *)vcache,
-                           d_slot, d_pos, d_kv_idx, (bf16_t *)out, n, H, d, n_text_ctx);
+        hipLaunchKernelGGL(self_attn_lean_kernel<bf16_t>, dim3(n * H), dim3(MT), 0, st, q, (const bf16_t *)kcache, (const bf16_t *)vcache,
+                           d_slot, d_pos, d_kv_idx, (bf16_t *)out, H, d, n_text_ctx);
     MW_HIP(hipGetLastError());
 }
 
