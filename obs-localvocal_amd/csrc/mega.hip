@@ -1066,6 +1066,116 @@ __device__ __forceinline__ void cross_attn_phase_mfma(const float *q, const bf16
     }
 }
 
+// ---- cross-attention on the matrix cores as a straight-line kernel of its own (one (head, split) per workgroup) ----
+// Same arithmetic as cross_attn_phase_mfma; differences: every global load is unconditional (keys beyond the split
+// are clamped to its last key and masked in the scores) and issued before anything else; K is loaded like V, 8 lanes
+// per 128-byte head row (whole cache lines per instruction), and re-read from LDS in the B-fragment layout; no LDS
+// zero-fill (operand rows beyond the real rows only feed result rows nobody reads).
+constexpr int XKD = 64 + 8;  // LDS row stride of the [key][dim] K tile
+
+template <int NB, typename OT>
+__device__ __forceinline__ void cross_attn_lean(const float *q, const bf16_t *kc, const bf16_t *vc, float *part, OT *out,
+                                                unsigned *head_cnt, int n, int H, int d, int n_ctx, int splits, int per, float *lds) {
+    bf16_t *qb = reinterpret_cast<bf16_t *>(lds);  // [16][72]    q rows
+    bf16_t *kt = qb + 16 * 72;                     // [XK][XKD]   K rows
+    bf16_t *vt = kt + XK * XKD;                    // [64][XLDP]  V transposed: [dim][key]
+    bf16_t *pb = vt + 64 * XLDP;                   // [16][XLDP]  probabilities
+    float *sc = reinterpret_cast<float *>(pb + 16 * XLDP);  // [NB][XK] scores; reused by the combine
+    float *red = sc + (NB * XK > 2 * NB * CROSS_SPLITS_MAX ? NB * XK : 2 * NB * CROSS_SPLITS_MAX);  // [8][64][4]
+    float *ml = red + 8 * 64 * 4;                  // [NB][2]
+    unsigned *flag = reinterpret_cast<unsigned *>(ml + NB * 2);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+    const int h = blockIdx.x / splits, sp = blockIdx.x - h * splits;
+    const int j0 = sp * per, nk = min(per, n_ctx - j0);  // may be <= 0 for a trailing split
+    const int last = max(nk - 1, 0) + min(j0, n_ctx - 1);  // a valid key for clamped loads
+    // ---- loads ----
+    const int qi = min(tid, NB * 64 - 1);
+    const float qv = q[(long)min(qi >> 6, n - 1) * d + h * 64 + (qi & 63)];
+    const int kk = tid >> 3, e8 = tid & 7;
+    u32x4v kq[2], vq[2];  // first-class vectors: component access stays in registers
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int key = kk + 64 * i;
+        const long off = (long)(key < nk ? j0 + key : last) * d + h * 64 + e8 * 8;
+        kq[i] = *reinterpret_cast<const u32x4v *>(kc + off);
+        vq[i] = *reinterpret_cast<const u32x4v *>(vc + off);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- stage q, K and V^T ----
+    qb[(qi >> 6) * 72 + (qi & 63)] = to_bf16(qv);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int key = kk + 64 * i;
+        *reinterpret_cast<u32x4v *>(kt + key * XKD + e8 * 8) = kq[i];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            vt[(e8 * 8 + 2 * c) * XLDP + key] = (bf16_t)(vq[i][c] & 0xffffu);
+            vt[(e8 * 8 + 2 * c + 1) * XLDP + key] = (bf16_t)(vq[i][c] >> 16);
+        }
+    }
+    lds_sync();
+    // ---- scores: wave w -> keys 16w .. 16w+15 ----
+    {
+        const int kkey = 16 * wave + fr;
+        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const uint4 af = *reinterpret_cast<const uint4 *>(qb + fr * 72 + 32 * s2 + 8 * fq);
+            const uint4 bfr = *reinterpret_cast<const uint4 *>(kt + kkey * XKD + 32 * s2 + 8 * fq);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8b, af), __builtin_bit_cast(bf16x8b, bfr), acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * fq + r;
+            if (row < NB) sc[row * XK + kkey] = kkey < nk ? acc[r] : -INFINITY;
+        }
+    }
+    lds_sync();
+    // ---- per-row softmax over the split (wave w: row w) ----
+    if (wave < NB) {
+        const int r = wave;
+        const float v0 = sc[r * XK + lane], v1 = sc[r * XK + 64 + lane];
+        const float mx = wave_max_all(fmaxf(v0, v1));
+        const float e0 = lane < nk ? expf(v0 - mx) : 0.0f, e1 = (64 + lane) < nk ? expf(v1 - mx) : 0.0f;
+        const float sum = wave_sum_all(e0 + e1);
+        pb[r * XLDP + lane] = to_bf16(e0);
+        pb[r * XLDP + 64 + lane] = to_bf16(e1);
+        if (lane == 0) {
+            ml[r * 2] = mx;
+            ml[r * 2 + 1] = sum;
+        }
+    }
+    lds_sync();
+    // ---- P . V ----
+    {
+        const int nt = wave & 3, kh = wave >> 2;
+        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int ks = 2 * kh + s2;
+            const uint4 af = *reinterpret_cast<const uint4 *>(pb + fr * XLDP + 32 * ks + 8 * fq);
+            const uint4 bfr = *reinterpret_cast<const uint4 *>(vt + (16 * nt + fr) * XLDP + 32 * ks + 8 * fq);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8b, af), __builtin_bit_cast(bf16x8b, bfr), acc, 0, 0, 0);
+        }
+        *reinterpret_cast<f32x4 *>(red + (wave * 64 + lane) * 4) = acc;
+    }
+    lds_sync();
+    if (tid < NB * 64) {
+        const int r = tid >> 6, e = tid & 63;
+        if (r < n) {
+            const int nt = e >> 4, src_lane = (r >> 2) * 16 + (e & 15), rr = r & 3;
+            const float v = red[(nt * 64 + src_lane) * 4 + rr] + red[((4 + nt) * 64 + src_lane) * 4 + rr];
+            float *pp = part + (((long)r * H + h) * splits + sp) * CPART;
+            st_agent(pp + 2 + e, v);
+            if (e == 0) {
+                st_agent(pp, ml[r * 2]);
+                st_agent(pp + 1, ml[r * 2 + 1]);
+            }
+        }
+    }
+    cross_count_and_combine<NB, OT>(part, out, head_cnt, sc, flag, n, H, d, h, splits);
+}
+
 // optional per-phase timestamps (a.prof != null): MEGA_PROF_STRIDE wall-clock samples per (layer, workgroup)
 #define MEGA_STAMP(i)                                                                                              \
     do {                                                                                                           \
@@ -1219,6 +1329,15 @@ __global__ __launch_bounds__(MEGA_THREADS) void proj_res_tile_kernel(Proj p, con
 }
 
 template <int NB, typename OT>
+__global__ __launch_bounds__(MEGA_THREADS) void cross_attn_lean_kernel(const float *q, const bf16_t *kc, const bf16_t *vc, float *part,
+                                                                        OT *out, unsigned *head_cnt, int n, int H, int d, int n_ctx,
+                                                                        int splits, int per) {
+    __shared__ __attribute__((aligned(16))) float lds[(16 * 72 + XK * XKD + 64 * XLDP + 16 * XLDP) / 2 + NB * XK +
+                                                      2 * NB * CROSS_SPLITS_MAX + 8 * 64 * 4 + NB * 2 + 16];
+    cross_attn_lean<NB, OT>(q, kc, vc, part, out, head_cnt, n, H, d, n_ctx, splits, per, lds);
+}
+
+template <int NB, typename OT>
 __global__ __launch_bounds__(MEGA_THREADS) void cross_attn_mfma_kernel(const float *q, const bf16_t *kc, const bf16_t *vc, float *part,
                                                                         OT *out, unsigned *head_cnt, int n, int H, int d, int n_ctx,
                                                                         int splits, int per) {
@@ -1326,7 +1445,7 @@ void launch_cross_attn_wg(const float *q, const void *kc, const void *vc, float 
 #define MW_CROSS(NBv, OTv)                                                                                                          \
     do {                                                                                                                            \
         if (mfma)                                                                                                                   \
-            hipLaunchKernelGGL((cross_attn_mfma_kernel<NBv, OTv>), grid, block, 0, st, q, (const bf16_t *)kc, (const bf16_t *)vc,   \
+            hipLaunchKernelGGL((cross_attn_lean_kernel<NBv, OTv>), grid, block, 0, st, q, (const bf16_t *)kc, (const bf16_t *)vc,   \
                                partial, (OTv *)out, head_cnt, n, H, d, n_ctx, splits, per);                                        \
         else                                                                                                                        \
             hipLaunchKernelGGL((cross_attn_wg_kernel<NBv, OTv>), grid, block, 0, st, q, (const bf16_t *)kc, (const bf16_t *)vc,     \
