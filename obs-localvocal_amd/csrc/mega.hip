@@ -752,44 +752,32 @@ __device__ __forceinline__ void cross_count_and_combine(const float *part, OT *o
             *flag = last;
         }
         lds_sync();
-        if (*flag) {  // every split of head h is in memory: combine in fixed split order, loads first
-            float *cm = sc, *cl = sc + NB * CROSS_SPLITS_MAX;  // split maxima / sums of all rows, staged in LDS
-            for (int i = tid; i < NB * CROSS_SPLITS_MAX; i += MT) {
-                const int r = i / CROSS_SPLITS_MAX, sidx = i - r * CROSS_SPLITS_MAX;
-                const bool on = r < n && sidx < splits;
-                const float *pp = part + (((long)r * H + h) * splits + (on ? sidx : 0)) * CPART;
-                cm[i] = on ? pp[0] : -INFINITY;
-                cl[i] = on ? pp[1] : 0.0f;
+        if (*flag) {  // every split of head h is in memory: combine in fixed split order
+            // one batch of unconditional loads per thread (row r, dim e): the splits' (max, sum) pairs — the same
+            // address for the 64 threads of a row — and the thread's own partial outputs; surplus slots repeat the
+            // last split and get weight zero
+            const int i = min(tid, NB * 64 - 1), r = min(i >> 6, n - 1), e = i & 63;
+            const float *pp = part + ((long)r * H + h) * splits * CPART;
+            float2 mlv[CROSS_SPLITS_MAX];
+            float ov[CROSS_SPLITS_MAX];
+#pragma unroll
+            for (int sidx = 0; sidx < CROSS_SPLITS_MAX; ++sidx) {
+                const float *ps = pp + min(sidx, splits - 1) * CPART;
+                mlv[sidx] = *reinterpret_cast<const float2 *>(ps);
+                ov[sidx] = ps[2 + e];
             }
-            float ov[(NB * 64 + MT - 1) / MT][CROSS_SPLITS_MAX];
+            float M = -INFINITY;
 #pragma unroll
-            for (int u = 0; u < (NB * 64 + MT - 1) / MT; ++u) {
-                const int i = tid + u * MT, r = i >> 6, e = i & 63;
-                const bool rowon = i < NB * 64 && r < n;
-                const float *pp = part + ((long)(rowon ? r : 0) * H + h) * splits * CPART;
+            for (int sidx = 0; sidx < CROSS_SPLITS_MAX; ++sidx) M = fmaxf(M, sidx < splits ? mlv[sidx].x : -INFINITY);
+            float Lsum = 0.0f, acc = 0.0f;
 #pragma unroll
-                for (int sidx = 0; sidx < CROSS_SPLITS_MAX; ++sidx)
-                    ov[u][sidx] = (rowon && sidx < splits) ? pp[sidx * CPART + 2 + e] : 0.0f;
+            for (int sidx = 0; sidx < CROSS_SPLITS_MAX; ++sidx) {
+                const float mm = sidx < splits ? mlv[sidx].x : -INFINITY;
+                const float w = mm > -INFINITY ? expf(mm - M) : 0.0f;
+                Lsum += w * mlv[sidx].y;
+                acc += w * ov[sidx];
             }
-            lds_sync();
-#pragma unroll
-            for (int u = 0; u < (NB * 64 + MT - 1) / MT; ++u) {
-                const int i = tid + u * MT, r = i >> 6, e = i & 63;
-                if (i < NB * 64 && r < n) {
-                    float M = -INFINITY;
-#pragma unroll
-                    for (int sidx = 0; sidx < CROSS_SPLITS_MAX; ++sidx) M = fmaxf(M, cm[r * CROSS_SPLITS_MAX + sidx]);
-                    float Lsum = 0.0f, acc = 0.0f;
-#pragma unroll
-                    for (int sidx = 0; sidx < CROSS_SPLITS_MAX; ++sidx) {
-                        const float mm = cm[r * CROSS_SPLITS_MAX + sidx];
-                        const float w = mm > -INFINITY ? expf(mm - M) : 0.0f;
-                        Lsum += w * cl[r * CROSS_SPLITS_MAX + sidx];
-                        acc += w * ov[u][sidx];
-                    }
-                    st_out(out + (long)r * d + h * 64 + e, acc / Lsum);
-                }
-            }
+            if (tid < NB * 64 && (tid >> 6) < n) st_out(out + (long)r * d + h * 64 + e, acc / Lsum);
         }
 }
 
