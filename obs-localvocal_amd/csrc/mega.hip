@@ -493,32 +493,33 @@ __device__ __forceinline__ void proj_ln_tile(const Proj &p, const float *xin, co
 // 64*SPC contiguous bytes); each chunk is transposed into the fragment layout through a wave-private LDS tile
 // (LDS operations of one wave execute in order: no barrier), so the only workgroup barrier is the one before
 // the 8 partial tiles are summed.
-template <int NB, int SPC, int CH>
+template <int NB, int SPC, int CH, int FR>
 __device__ __forceinline__ void proj_res_tile(const Proj &p, const bf16_t *xin, int n, const Epi &e, bf16_t *lds_t, float *red,
                                               unsigned long long *stamp) {
     constexpr int KC = 32 * SPC, LDT = KC + 8, PPR = 4 * SPC;  // k per chunk, LDS row stride, 16-byte pieces per row segment
     constexpr int XLD = CH * KC + 8, XPR = PPR * CH;           // the wave's x tile: row stride, pieces per row
     constexpr int XI = (NB * XPR + 63) / 64;                   // x load instructions
+    constexpr int WI = (FR * PPR + 63) / 64;                   // weight load instructions per chunk (FR feature rows per workgroup)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
     const int K = p.K, tile = blockIdx.x, kw = wave * CH * KC;
     u32x4v xv[XI];  // first-class vectors: as HIP uint4 structs this array was not split into registers and went through
                     // LDS scratch, whose indexing reads the workgroup size from the dispatch packet in host memory (2-6 us)
-    uint4 w[CH][SPC];
+    uint4 w[CH][WI];
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
         const int pc = min(lane + 64 * i, NB * XPR - 1);
         xv[i] = *reinterpret_cast<const u32x4v *>(xin + (long)min(pc / XPR, n - 1) * K + kw + 8 * (pc % XPR));
     }
-    const int el = (tid & 255) >> 2, er = tid & 3, erow = 4 * (el >> 4) + er, n_e = tile * 16 + (el & 15);
+    const int el = (tid & 255) >> 2, er = tid & 3, erow = 4 * (el >> 4) + er, n_e = tile * FR + min(el & 15, FR - 1);
     const float res_e = e.res[(long)(erow < n ? erow : 0) * p.N + n_e];
     const float bias_v = (p.bias ? p.bias : e.res)[n_e];  // unconditional load: a branch here would split the load block
     const float bias_e = p.bias ? bias_v : 0.0f;
 #pragma unroll
     for (int c = 0; c < CH; ++c)
 #pragma unroll
-        for (int j = 0; j < SPC; ++j) {
-            const int pc = lane + 64 * j;
-            w[c][j] = ld_stream16(p.W + (long)(tile * 16 + pc / PPR) * K + kw + c * KC + 8 * (pc % PPR));
+        for (int j = 0; j < WI; ++j) {
+            const int pc = min(lane + 64 * j, FR * PPR - 1);
+            w[c][j] = ld_stream16(p.W + (long)(tile * FR + pc / PPR) * K + kw + c * KC + 8 * (pc % PPR));
         }
     __builtin_amdgcn_sched_barrier(0);  // every load above is issued before anything below (no sinking next to the use)
     bf16_t *wt = lds_t + wave * (16 * LDT + NB * XLD), *xt = wt + 16 * LDT;
@@ -532,8 +533,8 @@ __device__ __forceinline__ void proj_res_tile(const Proj &p, const bf16_t *xin, 
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
 #pragma unroll
-        for (int j = 0; j < SPC; ++j) {
-            const int pc = lane + 64 * j;
+        for (int j = 0; j < WI; ++j) {
+            const int pc = min(lane + 64 * j, FR * PPR - 1);  // surplus lanes rewrite the last piece
             *reinterpret_cast<uint4 *>(wt + (pc / PPR) * LDT + 8 * (pc % PPR)) = w[c][j];
         }
 #pragma unroll
@@ -547,7 +548,7 @@ __device__ __forceinline__ void proj_res_tile(const Proj &p, const bf16_t *xin, 
     *reinterpret_cast<f32x4 *>(red + (wave * 64 + lane) * 4) = acc;
     lds_sync();
     if (stamp && tid == 0) stamp[2] = wall_clock64();
-    if (tid < 256 && erow < n) {
+    if (tid < 256 && erow < n && (el & 15) < FR) {  // tile columns beyond FR come from unwritten LDS rows: ignored
         float r = 0.0f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) r += red[(k * 64 + el) * 4 + er];
@@ -1309,11 +1310,11 @@ __global__ __launch_bounds__(MEGA_THREADS) void proj_ln_tile_kernel(Proj p, cons
     proj_ln_tile<NB, EPI>(p, xin, ln_w, ln_b, n, e, xs, wt, red, nullptr);
 }
 
-template <int NB, int SPC, int CH>
+template <int NB, int SPC, int CH, int FR>
 __global__ __launch_bounds__(MEGA_THREADS) void proj_res_tile_kernel(Proj p, const bf16_t *xin, int n, Epi e) {
     __shared__ __attribute__((aligned(16))) bf16_t lds_t[8 * (16 * (32 * SPC + 8) + NB * (CH * 32 * SPC + 8))];
     __shared__ __attribute__((aligned(16))) float red[8 * 64 * 4];
-    proj_res_tile<NB, SPC, CH>(p, xin, n, e, lds_t, red, nullptr);
+    proj_res_tile<NB, SPC, CH, FR>(p, xin, n, e, lds_t, red, nullptr);
 }
 
 template <int NB, typename OT>
@@ -1378,8 +1379,14 @@ void launch_proj_wg(const GemvArgs &a, hipStream_t st) {
         MW_CHECK(a.x_bf16 && a.R && a.ldo == a.N && a.act == ACT_NONE && a.out_scale == 1.0f && spw <= 20, "proj_wg: residual class");
         e.res = a.R; e.xout = a.out;
         const int ch = a.K > 1280 ? 4 : 1, spc = a.K / (256 * ch);  // K = 8 waves x CH chunks x SPC steps x 32
-#define MW_RES(NBv, SPCv, CHv) \
-    hipLaunchKernelGGL((proj_res_tile_kernel<NBv, SPCv, CHv>), grid, block, 0, st, p, (const bf16_t *)a.x, a.n, e)
+        static const bool res16 = getenv("MI355_WHISPER_RES16") != nullptr;  // 16-feature tiles for K = 4d too
+#define MW_RES(NBv, SPCv, CHv)                                                                                                  \
+    do {                                                                                                                        \
+        if (CHv == 4 && !res16)                                                                                                 \
+            hipLaunchKernelGGL((proj_res_tile_kernel<NBv, SPCv, CHv, 8>), dim3(a.N / 8), block, 0, st, p, (const bf16_t *)a.x, a.n, e);  \
+        else                                                                                                                    \
+            hipLaunchKernelGGL((proj_res_tile_kernel<NBv, SPCv, CHv, 16>), grid, block, 0, st, p, (const bf16_t *)a.x, a.n, e); \
+    } while (0)
 #define MW_RES_SPC(SPCv)                                    \
     do {                                                     \
         if (a.n == 1 && ch == 1) MW_RES(1, SPCv, 1);         \

@@ -48,14 +48,14 @@ __global__ __launch_bounds__(MEGA_THREADS) void proj_probe_ln(Proj p, const void
         for (int k = 0; k < 6; ++k) stamps[(size_t)blockIdx.x * NST + k] = s[k];
 }
 
-template <int NB, int SPC, int CH>
+template <int NB, int SPC, int CH, int FR>
 __global__ __launch_bounds__(MEGA_THREADS) void proj_probe_res(Proj p, const bf16_t *xin, int n, Epi e, unsigned long long *stamps) {
     __shared__ __attribute__((aligned(16))) bf16_t lds_t[8 * (16 * (32 * SPC + 8) + NB * (CH * 32 * SPC + 8))];
     __shared__ __attribute__((aligned(16))) float red[8 * 64 * 4];
     __shared__ unsigned long long s[NST];  // stamps stay in LDS until the end: a global store at entry would be
                                            // waited for (vmcnt) together with the first loads and distort them
     if (threadIdx.x == 0) s[4] = wall_clock64();
-    proj_res_tile<NB, SPC, CH>(p, xin, n, e, lds_t, red, s);
+    proj_res_tile<NB, SPC, CH, FR>(p, xin, n, e, lds_t, red, s);
     __syncthreads();
     if (threadIdx.x == 0) s[5] = wall_clock64();
     if (threadIdx.x == 0)
@@ -179,9 +179,9 @@ int main() {
                 hipLaunchKernelGGL(producer_bf16, dim3((n * c.K + 255) / 256), dim3(256), 0, st, xb, n * c.K, tprod);
 #endif
                 if (c.lean && c.K <= 1280)
-                    hipLaunchKernelGGL((proj_probe_res<5, 5, 1>), dim3(wgs), dim3(MEGA_THREADS), 0, st, p, (const bf16_t *)xb, n, e, stamps);
+                    hipLaunchKernelGGL((proj_probe_res<5, 5, 1, 16>), dim3(wgs), dim3(MEGA_THREADS), 0, st, p, (const bf16_t *)xb, n, e, stamps);
                 else if (c.lean)
-                    hipLaunchKernelGGL((proj_probe_res<5, 5, 4>), dim3(wgs), dim3(MEGA_THREADS), 0, st, p, (const bf16_t *)xb, n, e, stamps);
+                    hipLaunchKernelGGL((proj_probe_res<5, 5, 4, 8>), dim3(2 * wgs), dim3(MEGA_THREADS), 0, st, p, (const bf16_t *)xb, n, e, stamps);
                 else if (c.K <= 1280)
                     hipLaunchKernelGGL((proj_probe<5, false, EPI_RES, 5>), dim3(wgs), dim3(MEGA_THREADS), 0, st, p, (const void *)xb, nullptr,
                                        nullptr, n, e, stamps);
