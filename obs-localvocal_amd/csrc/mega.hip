@@ -387,7 +387,7 @@ __device__ __forceinline__ void proj_finish(float v, int erow, int n_e, const Pr
 // 2w and 2w+1 as consecutive 1 KB pieces — and re-read from LDS in the MFMA B-fragment layout.  Loading the
 // fragments straight from global memory touches 64 cache lines per instruction (16 bytes of each) instead of
 // 8 and was 1.3-1.4 us slower per launch (tools/microbench/mb_latency, "B-fragment pattern").
-template <int NB, int EPI>
+template <int NB, int EPI, int FR>
 __device__ __forceinline__ void proj_ln_tile(const Proj &p, const float *xin, const float *ln_w, const float *ln_b, int n, const Epi &e,
                                              bf16_t *xs, bf16_t *wt, float *red, unsigned long long *stamp) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
@@ -406,14 +406,15 @@ __device__ __forceinline__ void proj_ln_tile(const Proj &p, const float *xin, co
         gw[i] = *reinterpret_cast<const float4 *>(ln_w + c);
         gb[i] = *reinterpret_cast<const float4 *>(ln_b + c);
     }
-    uint4 w[5];
-    const int wpieces = K >> 2;  // 16-byte pieces in the wave's two rows
+    constexpr int RPW = FR / 8, WJ = FR == 16 ? 5 : 3;  // weight rows per wave, load instructions per wave
+    uint4 w[WJ];
+    const int wpieces = RPW * (K >> 3);  // 16-byte pieces in the wave's row(s)
     {
-        const bf16_t *wbase = p.W + (long)(tile * 16 + 2 * wave) * K;
+        const bf16_t *wbase = p.W + (long)(tile * FR + RPW * wave) * K;
 #pragma unroll
-        for (int j = 0; j < 5; ++j) w[j] = ld_stream16(wbase + 8 * min(lane + 64 * j, wpieces - 1));
+        for (int j = 0; j < WJ; ++j) w[j] = ld_stream16(wbase + 8 * min(lane + 64 * j, wpieces - 1));
     }
-    const int el = (tid & 255) >> 2, er = tid & 3, erow = 4 * (el >> 4) + er, n_e = tile * 16 + (el & 15);
+    const int el = (tid & 255) >> 2, er = tid & 3, erow = 4 * (el >> 4) + er, n_e = tile * FR + min(el & 15, FR - 1);
     const float bias_e = p.bias ? p.bias[n_e] : 0.0f;
     long kv_off = 0;
     if constexpr (EPI == EPI_QKV) {
@@ -445,10 +446,10 @@ __device__ __forceinline__ void proj_ln_tile(const Proj &p, const float *xin, co
     if (stamp && tid == 0) stamp[0] = wall_clock64();
     // ---- the wave's two weight rows -> LDS ----
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
+    for (int j = 0; j < WJ; ++j) {
         const int pc = lane + 64 * j, half = K >> 3;  // pieces per row
         const int r = pc >= half ? 1 : 0;
-        if (pc < wpieces) *reinterpret_cast<uint4 *>(wt + (2 * wave + r) * ldxs + 8 * (pc - r * half)) = w[j];
+        if (pc < wpieces) *reinterpret_cast<uint4 *>(wt + (RPW * wave + r) * ldxs + 8 * (pc - r * half)) = w[j];
     }
     lds_sync();
     if (stamp && tid == 0) stamp[1] = wall_clock64();
@@ -470,7 +471,7 @@ __device__ __forceinline__ void proj_ln_tile(const Proj &p, const float *xin, co
     lds_sync();
     if (stamp && tid == 0) stamp[2] = wall_clock64();
     // ---- finish: fixed-order sum of the 8 partial tiles, bias, epilogue ----
-    if (tid < 256 && erow < n) {
+    if (tid < 256 && erow < n && (el & 15) < FR) {  // tile columns beyond FR come from unwritten LDS rows: ignored
         float r = 0.0f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) r += red[(k * 64 + el) * 4 + er];
@@ -1301,13 +1302,13 @@ __global__ __launch_bounds__(MEGA_THREADS) void proj_wg_kernel(Proj p, const voi
     proj_phase<NB, LN, EPI, 1, J, true>(nullptr, w, p, xin, ln_w, ln_b, n, e, lds);
 }
 
-template <int NB, int EPI>
+template <int NB, int EPI, int FR>
 __global__ __launch_bounds__(MEGA_THREADS) void proj_ln_tile_kernel(Proj p, const float *xin, const float *ln_w, const float *ln_b, int n,
                                                                      Epi e) {
     __shared__ __attribute__((aligned(16))) bf16_t xs[NB * (256 * LN_MAX_F4 + 8)];
-    __shared__ __attribute__((aligned(16))) bf16_t wt[16 * (256 * LN_MAX_F4 + 8)];
+    __shared__ __attribute__((aligned(16))) bf16_t wt[FR * (256 * LN_MAX_F4 + 8)];
     __shared__ __attribute__((aligned(16))) float red[8 * 64 * 4];
-    proj_ln_tile<NB, EPI>(p, xin, ln_w, ln_b, n, e, xs, wt, red, nullptr);
+    proj_ln_tile<NB, EPI, FR>(p, xin, ln_w, ln_b, n, e, xs, wt, red, nullptr);
 }
 
 template <int NB, int SPC, int CH, int FR>
@@ -1346,10 +1347,18 @@ void launch_proj_wg(const GemvArgs &a, hipStream_t st) {
     Proj p{(const bf16_t *)a.W, a.bias, a.N, a.K, 0};
     Epi e{};
     const dim3 grid(a.N / 16), block(MT);
+    // 8-feature tiles (twice the workgroups) for projections of at most this many features (env for experiments)
+    static const int ln8_max_n = getenv("MI355_WHISPER_LN8_MAX_N") ? atoi(getenv("MI355_WHISPER_LN8_MAX_N")) : 1280;
 #define MW_PROJ(NBv, LNv, EPIv, Jv) \
     hipLaunchKernelGGL((proj_wg_kernel<NBv, LNv, EPIv, Jv>), grid, block, 0, st, p, (const void *)a.x, a.ln_w, a.ln_b, a.n, e)
-#define MW_PROJ_LN(NBv, EPIv) \
-    hipLaunchKernelGGL((proj_ln_tile_kernel<NBv, EPIv>), grid, block, 0, st, p, (const float *)a.x, a.ln_w, a.ln_b, a.n, e)
+#define MW_PROJ_LN(NBv, EPIv)                                                                                                       \
+    do {                                                                                                                            \
+        if (a.N <= ln8_max_n)                                                                                                       \
+            hipLaunchKernelGGL((proj_ln_tile_kernel<NBv, EPIv, 8>), dim3(a.N / 8), block, 0, st, p, (const float *)a.x, a.ln_w, a.ln_b, \
+                               a.n, e);                                                                                             \
+        else                                                                                                                        \
+            hipLaunchKernelGGL((proj_ln_tile_kernel<NBv, EPIv, 16>), grid, block, 0, st, p, (const float *)a.x, a.ln_w, a.ln_b, a.n, e); \
+    } while (0)
 #define MW_PROJ_NB(LNv, EPIv, Jv)                \
     do {                                          \
         if (a.n == 1) MW_PROJ(1, LNv, EPIv, Jv);  \
@@ -1379,13 +1388,13 @@ void launch_proj_wg(const GemvArgs &a, hipStream_t st) {
         MW_CHECK(a.x_bf16 && a.R && a.ldo == a.N && a.act == ACT_NONE && a.out_scale == 1.0f && spw <= 20, "proj_wg: residual class");
         e.res = a.R; e.xout = a.out;
         const int ch = a.K > 1280 ? 4 : 1, spc = a.K / (256 * ch);  // K = 8 waves x CH chunks x SPC steps x 32
-        static const bool res16 = getenv("MI355_WHISPER_RES16") != nullptr;  // 16-feature tiles for K = 4d too
+        static const bool res16 = getenv("MI355_WHISPER_RES16") != nullptr;  // 16-feature tiles (default: 8)
 #define MW_RES(NBv, SPCv, CHv)                                                                                                  \
     do {                                                                                                                        \
-        if (CHv == 4 && !res16)                                                                                                 \
-            hipLaunchKernelGGL((proj_res_tile_kernel<NBv, SPCv, CHv, 8>), dim3(a.N / 8), block, 0, st, p, (const bf16_t *)a.x, a.n, e);  \
-        else                                                                                                                    \
+        if (res16)                                                                                                              \
             hipLaunchKernelGGL((proj_res_tile_kernel<NBv, SPCv, CHv, 16>), grid, block, 0, st, p, (const bf16_t *)a.x, a.n, e); \
+        else                                                                                                                    \
+            hipLaunchKernelGGL((proj_res_tile_kernel<NBv, SPCv, CHv, 8>), dim3(a.N / 8), block, 0, st, p, (const bf16_t *)a.x, a.n, e);  \
     } while (0)
 #define MW_RES_SPC(SPCv)                                    \
     do {                                                     \

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(MEGA_THREADS) void proj_probe_ln(Proj p, const void
     __shared__ unsigned long long s[NST];  // stamps stay in LDS until the end: a global store at entry would be
                                            // waited for (vmcnt) together with the first loads and distort them
     if (threadIdx.x == 0) s[4] = wall_clock64();
-    proj_ln_tile<NB, EPI>(p, (const float *)xin, ln_w, ln_b, n, e, xs, wt, red, s);
+    proj_ln_tile<NB, EPI, 16>(p, (const float *)xin, ln_w, ln_b, n, e, xs, wt, red, s);
     __syncthreads();
     if (threadIdx.x == 0) s[5] = wall_clock64();
     if (threadIdx.x == 0)
