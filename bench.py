@@ -48,10 +48,10 @@ def load_package():
 
 
 GEMV_CLASSES = {"qkv": 0, "attn_out": 1, "cross_q": 2, "fc1": 3, "fc2": 4, "logits": 5, "cross_attn": 7}
-KERNEL_NAMES = {"qkv": "proj_wg_kernel<rows,LN,EPI_QKV>", "cross_q": "proj_wg_kernel<rows,LN,EPI_SCALE>",
-                "fc1": "proj_wg_kernel<rows,LN,EPI_GELU>", "attn_out": "gemv_kernel<bf16,class=attn_out>",
-                "fc2": "gemv_kernel<bf16,class=fc2>", "logits": "gemv_kernel<bf16,class=logits>",
-                "cross_attn": "cross_attn_wg_kernel<rows>"}
+KERNEL_NAMES = {"qkv": "proj_ln_tile_kernel<rows,EPI_QKV,16>", "cross_q": "proj_ln_tile_kernel<rows,EPI_SCALE,8>",
+                "fc1": "proj_ln_tile_kernel<rows,EPI_GELU_BF16,16>", "attn_out": "proj_res_tile_kernel<rows,5,1,8>",
+                "fc2": "proj_res_tile_kernel<rows,5,4,8>", "logits": "gemv_kernel<bf16,class=logits>",
+                "cross_attn": "cross_attn_lean_kernel<rows>"}
 
 
 def gemv_bytes(cls: str, d: int, n_vocab: int, rows: int, wbytes: int, n_audio_ctx: int = 1500) -> int:
@@ -61,7 +61,9 @@ def gemv_bytes(cls: str, d: int, n_vocab: int, rows: int, wbytes: int, n_audio_c
     N, K = {"qkv": (3 * d, d), "attn_out": (d, d), "cross_q": (d, d), "fc1": (4 * d, d), "fc2": (d, 4 * d),
             "logits": (n_vocab, d)}[cls]
     resid = cls in ("attn_out", "fc2")
-    return N * K * wbytes + N * 4 + rows * K * 4 + rows * N * 4 * (2 if resid else 1)
+    x_b = 2 if resid and wbytes == 2 else 4   # rows between attention / MLP kernels and the residual projections are bf16
+    o_b = 2 if cls == "fc1" and wbytes == 2 else 4
+    return N * K * wbytes + N * 4 + rows * K * x_b + rows * N * o_b * (2 if resid else 1)
 
 
 def cpu_baseline(model_path: str, pcm: np.ndarray, beam: int, decode_steps: int, sample_steps: int, threads: int):

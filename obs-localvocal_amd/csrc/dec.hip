@@ -558,6 +558,15 @@ __global__ __launch_bounds__(256) void kv_reorder_kernel(const int *__restrict__
         new_idx[j * n_text_ctx + p] = p < n_past ? old_idx[s * n_text_ctx + p] : j;
 }
 
+__global__ __launch_bounds__(256) void kv_reorder_dev_kernel(const int *__restrict__ old_idx, int *__restrict__ new_idx,
+                                                             const int *__restrict__ args, int n_text_ctx) {
+    const int j = blockIdx.x;
+    const int s = args[j], n_past = args[KV_SLOTS];
+    if (args[KV_SLOTS + 1] == 0 || s < 0) return;
+    for (int p = threadIdx.x; p <= n_past; p += 256)
+        new_idx[j * n_text_ctx + p] = p < n_past ? old_idx[s * n_text_ctx + p] : j;
+}
+
 // rows-per-wave R is a property of the projection class: more output features per wave once N is large
 template <int TAG> struct TagR { static constexpr int v = (TAG == GEMV_LOGITS) ? 4 : ((TAG == GEMV_QKV || TAG == GEMV_FC1) ? 2 : 1); };
 
@@ -695,6 +704,11 @@ void launch_cross_attn(const float *q, const void *kc, const void *vc, DType kv_
         hipLaunchKernelGGL(cross_combine_kernel<float>, dim3(H, n), dim3(64), 0, st, partial, (float *)out, H, d, splits);
     else
         hipLaunchKernelGGL(cross_combine_kernel<bf16_t>, dim3(H, n), dim3(64), 0, st, partial, (bf16_t *)out, H, d, splits);
+    MW_HIP(hipGetLastError());
+}
+
+void launch_kv_reorder_dev(const int *old_idx, int *new_idx, const int *args, int n_text_ctx, hipStream_t st) {
+    hipLaunchKernelGGL(kv_reorder_dev_kernel, dim3(KV_SLOTS), dim3(256), 0, st, old_idx, new_idx, args, n_text_ctx);
     MW_HIP(hipGetLastError());
 }
 

@@ -46,13 +46,14 @@ Context::~Context() {
         (void)hipFree(d_mega_prof);
     }
     void *ptrs[] = {d_pcm, d_mel_raw, d_mel, d_gmax, d_conv_in, d_x1, d_h, d_qk, d_vt, d_p, d_att, d_ff, d_enc_out, d_x,
-                    d_s, d_cross, d_kself, d_vself, d_kv_idx[0], d_kv_idx[1], d_tokens, d_pos, d_slot, d_rows, d_xd, d_q,
+                    d_s, d_cross, d_kself, d_vself, d_kv_idx[0], d_kv_idx[1], d_tokens, d_xd, d_q,
                     d_attd, d_ffd, d_part, d_logits, d_work, d_suppress, d_row_state, d_row_res,
                     d_mega_layers, d_mega_act, d_mega_sync, d_xout, d_head_cnt};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h_mega_abort) (void)hipHostFree(h_mega_abort);
     if (h_ints) (void)hipHostFree(h_ints);
+    if (ev_staging) (void)hipEventDestroy(ev_staging);
     if (h_row_state) (void)hipHostFree(h_row_state);
     if (h_row_res) (void)hipHostFree(h_row_res);
     for (hipEvent_t e : prof_ev) (void)hipEventDestroy(e);
@@ -101,10 +102,10 @@ std::unique_ptr<Context> create_context(const unsigned char *data, size_t size, 
         dev_alloc(c->d_kv_idx[i], KV_SLOTS * TC);
         MW_HIP(hipMemsetAsync(c->d_kv_idx[i], 0, KV_SLOTS * TC * sizeof(int), c->st));
     }
-    dev_alloc(c->d_tokens, TC);
-    dev_alloc(c->d_pos, TC);
-    dev_alloc(c->d_slot, TC);
-    dev_alloc(c->d_rows, TC);
+    dev_alloc(c->d_tokens, 4 * TC);  // one block, laid out like the pinned staging block: tokens | pos | slot | rows + update args
+    c->d_pos = c->d_tokens + TC;
+    c->d_slot = c->d_tokens + 2 * TC;
+    c->d_rows = c->d_tokens + 3 * TC;
     dev_alloc(c->d_xd, TC * d);
     dev_alloc(c->d_q, TC * d);
     dev_alloc_bytes(c->d_attd, TC * d * 4);
@@ -115,7 +116,9 @@ std::unique_ptr<Context> create_context(const unsigned char *data, size_t size, 
     dev_alloc(c->d_suppress, nv);
     dev_alloc(c->d_row_state, LOGIT_ROWS);
     dev_alloc(c->d_row_res, LOGIT_ROWS);
+    MW_CHECK(TC >= LOGIT_ROWS + KV_SLOTS + 2, "n_text_ctx too small for the step block");
     MW_HIP(hipHostMalloc((void **)&c->h_ints, 4 * TC * sizeof(int)));
+    MW_HIP(hipEventCreateWithFlags(&c->ev_staging, hipEventDisableTiming));
     MW_HIP(hipHostMalloc((void **)&c->h_row_state, LOGIT_ROWS * sizeof(LogitsRowState)));
     MW_HIP(hipHostMalloc((void **)&c->h_row_res, LOGIT_ROWS * sizeof(LogitsRowResult)));
     c->decoders[0].rng = std::mt19937(0);
@@ -325,16 +328,31 @@ void encode(Context &c, int seek) {
 // decoder (A.4)
 // ------------------------------------------------------------------------------------------
 void kv_clear(Context &c) {
+    c.reorder_pending = false;  // superseded
     const size_t bytes = (size_t)KV_SLOTS * c.model.hp.n_text_ctx * sizeof(int);
     MW_HIP(hipMemsetAsync(c.d_kv_idx[0], 0, bytes, c.st));
     MW_HIP(hipMemsetAsync(c.d_kv_idx[1], 0, bytes, c.st));
     c.kv_cur = 0;
 }
 
-void kv_reorder(Context &c, const int *src, int n_past) {
+namespace {
+void flush_reorder(Context &c) {  // a deferred index-table update that no decode call picked up
+    if (!c.reorder_pending) return;
     BeamSrc b;
-    for (int j = 0; j < KV_SLOTS; ++j) b.src[j] = src[j];
-    launch_kv_reorder(c.d_kv_idx[c.kv_cur], c.d_kv_idx[c.kv_cur ^ 1], b, n_past, c.model.hp.n_text_ctx, c.st);
+    for (int j = 0; j < KV_SLOTS; ++j) b.src[j] = c.reorder_src[j];
+    launch_kv_reorder(c.d_kv_idx[c.kv_cur ^ 1], c.d_kv_idx[c.kv_cur], b, c.reorder_n_past, c.model.hp.n_text_ctx, c.st);
+    c.reorder_pending = false;
+}
+}  // namespace
+
+// The update runs as the first kernel of the next decode call's launch sequence (arguments travel in that call's
+// step block), so a beam step is one graph launch; the table parity flips here.
+void kv_reorder(Context &c, const int *src, int n_past) {
+    MW_CHECK(n_past >= 0 && n_past < c.model.hp.n_text_ctx, "kv reorder: position out of range");
+    flush_reorder(c);
+    for (int j = 0; j < KV_SLOTS; ++j) c.reorder_src[j] = src[j];
+    c.reorder_n_past = n_past;
+    c.reorder_pending = true;
     c.kv_cur ^= 1;
 }
 
@@ -370,24 +388,33 @@ void decode(Context &c, const int *tokens, const int *pos, const int *slot, int 
     const bool mf = c.mfma_proj || res_tile;  // bf16 rows between attention / MLP kernels and the projections
     const DType act_t = mf ? DType::BF16 : DType::F32;
     const double t0 = now_ms();
-    // the pinned staging block may still be read by the previous call's copies
-    MW_HIP(hipStreamSynchronize(st));
+    // the pinned staging block may still be read by the previous call's copy: wait for THAT call only (an event
+    // recorded behind it), not for whatever else is in flight on the stream
+    if (c.staging_pending) MW_HIP(hipEventSynchronize(c.ev_staging));
+    c.staging_pending = false;
+    if (c.use_mega) {
+        MW_HIP(hipStreamSynchronize(st));  // the abort word of the previous persistent launch must have landed
+        flush_reorder(c);
+    }
     check_mega(c);
     int *hi = c.h_ints;
     memcpy(hi, tokens, n * sizeof(int));
     memcpy(hi + TC, pos, n * sizeof(int));
     memcpy(hi + 2 * TC, slot, n * sizeof(int));
     memcpy(hi + 3 * TC, logit_rows, n_logit_rows * sizeof(int));
+    int *hu = hi + 3 * TC + LOGIT_ROWS;  // index-table update: src[KV_SLOTS], n_past, flag
+    for (int j = 0; j < KV_SLOTS; ++j) hu[j] = c.reorder_pending ? c.reorder_src[j] : -1;
+    hu[KV_SLOTS] = c.reorder_n_past;
+    hu[KV_SLOTS + 1] = c.reorder_pending ? 1 : 0;
+    c.reorder_pending = false;
+    const size_t step_bytes = (size_t)(3 * TC + LOGIT_ROWS + KV_SLOTS + 2) * sizeof(int);
     // Everything below is one fixed launch sequence for a given (rows, logits rows, index table, audio
     // context): it is captured into a hipGraph once and replayed, because the step is launch-bound
     // (~290 launches of 3-10 us kernels).  Per-step values (tokens, positions, slots) travel through
     // the pinned staging block and device arrays at fixed addresses, so the captured nodes stay valid.
     auto enqueue = [&]() {
-        MW_HIP(hipMemcpyAsync(c.d_tokens, hi, n * sizeof(int), hipMemcpyHostToDevice, st));
-        MW_HIP(hipMemcpyAsync(c.d_pos, hi + TC, n * sizeof(int), hipMemcpyHostToDevice, st));
-        MW_HIP(hipMemcpyAsync(c.d_slot, hi + 2 * TC, n * sizeof(int), hipMemcpyHostToDevice, st));
-        if (n_logit_rows)
-            MW_HIP(hipMemcpyAsync(c.d_rows, hi + 3 * TC, n_logit_rows * sizeof(int), hipMemcpyHostToDevice, st));
+        MW_HIP(hipMemcpyAsync(c.d_tokens, hi, step_bytes, hipMemcpyHostToDevice, st));  // the whole step block in one copy
+        launch_kv_reorder_dev(c.d_kv_idx[c.kv_cur ^ 1], c.d_kv_idx[c.kv_cur], c.d_rows + LOGIT_ROWS, TC, st);  // no-op without an update
         // launches of the profiled projection class are bracketed by HIP events (mw_profile_begin/end)
         auto gemv = [&](const GemvArgs &g) {
             const bool prof = g.tag == c.prof_tag && c.prof_n + 2 <= (int)c.prof_ev.size();
@@ -482,11 +509,7 @@ void decode(Context &c, const int *tokens, const int *pos, const int *slot, int 
     const bool use_graph = c.use_graphs && c.prof_tag < 0;
     if (c.use_mega && n <= 5 && c.prof_tag < 0) {
         // persistent path: embed, ONE cooperative kernel for all layers, then the logits projection
-        MW_HIP(hipMemcpyAsync(c.d_tokens, hi, n * sizeof(int), hipMemcpyHostToDevice, st));
-        MW_HIP(hipMemcpyAsync(c.d_pos, hi + TC, n * sizeof(int), hipMemcpyHostToDevice, st));
-        MW_HIP(hipMemcpyAsync(c.d_slot, hi + 2 * TC, n * sizeof(int), hipMemcpyHostToDevice, st));
-        if (n_logit_rows)
-            MW_HIP(hipMemcpyAsync(c.d_rows, hi + 3 * TC, n_logit_rows * sizeof(int), hipMemcpyHostToDevice, st));
+        MW_HIP(hipMemcpyAsync(c.d_tokens, hi, step_bytes, hipMemcpyHostToDevice, st));
         launch_embed(c.d_tokens, c.d_pos, m.tok_emb, wt, m.dec_pe, c.d_xd, n, d, st);
         MegaArgs a;
         a.layers = c.d_mega_layers;
@@ -540,6 +563,8 @@ void decode(Context &c, const int *tokens, const int *pos, const int *slot, int 
         }
         MW_HIP(hipGraphLaunch(it->second, st));
     }
+    MW_HIP(hipEventRecord(c.ev_staging, st));
+    c.staging_pending = true;
     c.n_logit_rows = n_logit_rows;
     c.tm.n_decode++;
     c.tm.decode_ms += now_ms() - t0;

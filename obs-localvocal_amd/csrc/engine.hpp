@@ -69,7 +69,12 @@ struct Context {
     LogitsRowState *d_row_state = nullptr;
     LogitsRowResult *d_row_res = nullptr;
     // pinned host staging
-    int *h_ints = nullptr;  // tokens | pos | slot | rows
+    int *h_ints = nullptr;  // tokens | pos | slot | rows + index-table update (src[KV_SLOTS], n_past, flag): one copy per step
+    hipEvent_t ev_staging = nullptr;  // recorded behind each decode launch: the staging block is free once it has passed
+    bool staging_pending = false;
+    // index-table update of the next decode call (kv_reorder defers it into that call's launch sequence)
+    bool reorder_pending = false;
+    int reorder_src[KV_SLOTS] = {0}, reorder_n_past = 0;
     LogitsRowState *h_row_state = nullptr;
     LogitsRowResult *h_row_res = nullptr;
     int n_logit_rows = 0;

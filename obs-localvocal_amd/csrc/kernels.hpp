@@ -133,6 +133,8 @@ struct BeamSrc {
     int src[KV_SLOTS];
 };
 void launch_kv_reorder(const int *old_idx, int *new_idx, BeamSrc src, int n_past, int n_text_ctx, hipStream_t st);
+// same update with its arguments in device memory: args = src[KV_SLOTS], n_past, flag (0: nothing to do) — graph-replayable
+void launch_kv_reorder_dev(const int *old_idx, int *new_idx, const int *args, int n_text_ctx, hipStream_t st);
 
 // ------------------------------------------------------------------------------------------
 // the decoder stack of one step as a single persistent cooperative kernel (mega.hip): bf16 weights, <= 5 rows

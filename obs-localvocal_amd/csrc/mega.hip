@@ -406,7 +406,8 @@ __device__ __forceinline__ void proj_ln_tile(const Proj &p, const float *xin, co
         gw[i] = *reinterpret_cast<const float4 *>(ln_w + c);
         gb[i] = *reinterpret_cast<const float4 *>(ln_b + c);
     }
-    constexpr int RPW = FR / 8, WJ = FR == 16 ? 5 : 3;  // weight rows per wave, load instructions per wave
+    constexpr int RPW = FR / 8, WJ = (RPW * 160 + 63) / 64;  // weight rows per wave, load instructions per wave (K <= 1280)
+    constexpr int TL = FR > 16 ? FR / 16 : 1;                // 16-feature MFMA tiles per workgroup
     uint4 w[WJ];
     const int wpieces = RPW * (K >> 3);  // 16-byte pieces in the wave's row(s)
     {
@@ -414,7 +415,8 @@ __device__ __forceinline__ void proj_ln_tile(const Proj &p, const float *xin, co
 #pragma unroll
         for (int j = 0; j < WJ; ++j) w[j] = ld_stream16(wbase + 8 * min(lane + 64 * j, wpieces - 1));
     }
-    const int el = (tid & 255) >> 2, er = tid & 3, erow = 4 * (el >> 4) + er, n_e = tile * FR + min(el & 15, FR - 1);
+    const int et = tid >> 8, el = (tid & 255) >> 2, er = tid & 3, erow = 4 * (el >> 4) + er;  // finisher: tile, lane, register
+    const int n_e = tile * FR + min(16 * et + (el & 15), FR - 1);
     const float bias_e = p.bias ? p.bias[n_e] : 0.0f;
     long kv_off = 0;
     if constexpr (EPI == EPI_QKV) {
@@ -448,7 +450,7 @@ __device__ __forceinline__ void proj_ln_tile(const Proj &p, const float *xin, co
 #pragma unroll
     for (int j = 0; j < WJ; ++j) {
         const int pc = lane + 64 * j, half = K >> 3;  // pieces per row
-        const int r = pc >= half ? 1 : 0;
+        const int r = (pc >= half ? 1 : 0) + (pc >= 2 * half ? 1 : 0) + (pc >= 3 * half ? 1 : 0);
         if (pc < wpieces) *reinterpret_cast<uint4 *>(wt + (RPW * wave + r) * ldxs + 8 * (pc - r * half)) = w[j];
     }
     lds_sync();
@@ -457,24 +459,31 @@ __device__ __forceinline__ void proj_ln_tile(const Proj &p, const float *xin, co
     {
         const bf16_t *arow = xs + (fr < n ? fr : 0) * ldxs + 8 * fq;  // rows >= n: any valid row, result ignored
         const bf16_t *brow = wt + fr * ldxs + 8 * fq;
-        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        f32x4 acc[TL];
+#pragma unroll
+        for (int tl = 0; tl < TL; ++tl) acc[tl] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
             const int step = wave + 8 * j, sc = min(step, ksteps - 1);
             const uint4 af = *reinterpret_cast<const uint4 *>(arow + 32 * sc);
-            uint4 wv = *reinterpret_cast<const uint4 *>(brow + 32 * sc);
-            if (step >= ksteps) wv = make_uint4(0, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8b, af), __builtin_bit_cast(bf16x8b, wv), acc, 0, 0, 0);
+#pragma unroll
+            for (int tl = 0; tl < TL; ++tl) {
+                uint4 wv = *reinterpret_cast<const uint4 *>(brow + 16 * tl * ldxs + 32 * sc);
+                if (step >= ksteps) wv = make_uint4(0, 0, 0, 0);
+                acc[tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8b, af), __builtin_bit_cast(bf16x8b, wv), acc[tl], 0,
+                                                                  0, 0);
+            }
         }
-        *reinterpret_cast<f32x4 *>(red + (wave * 64 + lane) * 4) = acc;
+#pragma unroll
+        for (int tl = 0; tl < TL; ++tl) *reinterpret_cast<f32x4 *>(red + ((tl * 8 + wave) * 64 + lane) * 4) = acc[tl];
     }
     lds_sync();
     if (stamp && tid == 0) stamp[2] = wall_clock64();
     // ---- finish: fixed-order sum of the 8 partial tiles, bias, epilogue ----
-    if (tid < 256 && erow < n && (el & 15) < FR) {  // tile columns beyond FR come from unwritten LDS rows: ignored
+    if (et < TL && erow < n && 16 * et + (el & 15) < FR) {  // tile columns beyond FR come from unwritten LDS rows: ignored
         float r = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) r += red[(k * 64 + el) * 4 + er];
+        for (int k = 0; k < 8; ++k) r += red[((et * 8 + k) * 64 + el) * 4 + er];
         r += bias_e;
         if constexpr (EPI == EPI_QKV) {
             const int d = e.d;
@@ -1307,7 +1316,7 @@ __global__ __launch_bounds__(MEGA_THREADS) void proj_ln_tile_kernel(Proj p, cons
                                                                      Epi e) {
     __shared__ __attribute__((aligned(16))) bf16_t xs[NB * (256 * LN_MAX_F4 + 8)];
     __shared__ __attribute__((aligned(16))) bf16_t wt[FR * (256 * LN_MAX_F4 + 8)];
-    __shared__ __attribute__((aligned(16))) float red[8 * 64 * 4];
+    __shared__ __attribute__((aligned(16))) float red[(FR > 16 ? FR / 16 : 1) * 8 * 64 * 4];
     proj_ln_tile<NB, EPI, FR>(p, xin, ln_w, ln_b, n, e, xs, wt, red, nullptr);
 }
 
@@ -1349,6 +1358,8 @@ void launch_proj_wg(const GemvArgs &a, hipStream_t st) {
     const dim3 grid(a.N / 16), block(MT);
     // 8-feature tiles (twice the workgroups) for projections of at most this many features (env for experiments)
     static const int ln8_max_n = getenv("MI355_WHISPER_LN8_MAX_N") ? atoi(getenv("MI355_WHISPER_LN8_MAX_N")) : 1280;
+    // 32-feature workgroups (two tiles, half the LayerNorm passes) for projections of at least this many features
+    static const int ln32_min_n = getenv("MI355_WHISPER_LN32_MIN_N") ? atoi(getenv("MI355_WHISPER_LN32_MIN_N")) : 4097;
 #define MW_PROJ(NBv, LNv, EPIv, Jv) \
     hipLaunchKernelGGL((proj_wg_kernel<NBv, LNv, EPIv, Jv>), grid, block, 0, st, p, (const void *)a.x, a.ln_w, a.ln_b, a.n, e)
 #define MW_PROJ_LN(NBv, EPIv)                                                                                                       \
@@ -1356,6 +1367,9 @@ void launch_proj_wg(const GemvArgs &a, hipStream_t st) {
         if (a.N <= ln8_max_n)                                                                                                       \
             hipLaunchKernelGGL((proj_ln_tile_kernel<NBv, EPIv, 8>), dim3(a.N / 8), block, 0, st, p, (const float *)a.x, a.ln_w, a.ln_b, \
                                a.n, e);                                                                                             \
+        else if (a.N >= ln32_min_n && a.N % 32 == 0)                                                                                \
+            hipLaunchKernelGGL((proj_ln_tile_kernel<NBv, EPIv, 32>), dim3(a.N / 32), block, 0, st, p, (const float *)a.x, a.ln_w,   \
+                               a.ln_b, a.n, e);                                                                                     \
         else                                                                                                                        \
             hipLaunchKernelGGL((proj_ln_tile_kernel<NBv, EPIv, 16>), grid, block, 0, st, p, (const float *)a.x, a.ln_w, a.ln_b, a.n, e); \
     } while (0)

@@ -16,10 +16,11 @@ import json
 import sys
 
 CLASS_OF = {  # kernel-name fragments -> bench.py roofline class
-    "cross_attn_wg_kernel": "cross_attn", "self_attn_wg_kernel": "self_attn",
-    "proj_wg_kernel<5, true, 0": "qkv", "proj_wg_kernel<5, true, 2": "cross_q", "proj_wg_kernel<5, true, 4": "fc1",
-    "gemv_kernel<unsigned short, unsigned short, 5, 1, 4>": "fc2", "gemv_kernel<unsigned short, unsigned short, 5, 1, 1>": "attn_out",
-    "gemv_kernel<unsigned short, unsigned short, 5, 4, 5>": "logits", "process_logits_kernel": "process_logits",
+    "cross_attn_lean_kernel": "cross_attn", "self_attn_lean_kernel": "self_attn",
+    "proj_ln_tile_kernel<5, 0": "qkv", "proj_ln_tile_kernel<5, 2": "cross_q", "proj_ln_tile_kernel<5, 3": "fc1",
+    "proj_res_tile_kernel<5, 5, 4": "fc2", "proj_res_tile_kernel<5, 5, 1": "attn_out",
+    "gemv_kernel<unsigned short, unsigned short, 5, 4, 5>": "logits", "logits_rules_kernel": "logits_rules",
+    "logits_sumexp_kernel": "logits_sumexp", "logits_stats_kernel": "logits_stats", "logits_sample_kernel": "logits_sample",
 }
 
 
