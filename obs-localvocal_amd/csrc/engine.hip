@@ -824,12 +824,17 @@ int full(Context &c, whisper_full_params params, const float *samples, int n_sam
     const int fds = c.force_decode_steps;
     int seek = seek_start;
     std::vector<int> prompt;
+    // a candidate = (source decoder, one of its sampled tokens); the sequence it stands for — the source's
+    // sequence plus that token — is only materialised for the candidates that are kept (whisper.cpp copies the
+    // sequence into every candidate: 55 vector copies per beam-5 step, ~20 us of host time between two steps)
     struct beam_candidate {
         int decoder_idx;
         int seek_delta;
         bool has_ts;
-        Sequence sequence;
+        whisper_token_data tk;
+        double sum_logprobs_all;  // of the candidate sequence: the sort key
     };
+    std::vector<Sequence> old_seq(n_decoders);
     std::vector<std::vector<beam_candidate>> bc_per_dec(n_decoders);
     std::vector<beam_candidate> beam_candidates;
     const bool beam = params.strategy == WHISPER_SAMPLING_BEAM_SEARCH;
@@ -900,9 +905,9 @@ int full(Context &c, whisper_full_params params, const float *samples, int n_sam
                     } else {
                         for (int k = 0; k < params.beam_search.beam_size; ++k) {
                             const whisper_token_data tk = make_token(vocab, d.sampled, k, vocab.beg);
-                            bc_per_dec[j].push_back({j, d.seek_delta, d.has_ts, d.sequence});
-                            bc_per_dec[j].back().sequence.tokens.push_back(tk);
-                            bc_per_dec[j].back().sequence.sum_logprobs_all += tk.plog;
+                            double sum_all = d.sequence.sum_logprobs_all;
+                            sum_all += tk.plog;
+                            bc_per_dec[j].push_back({j, d.seek_delta, d.has_ts, tk, sum_all});
                         }
                     }
                 }
@@ -913,20 +918,25 @@ int full(Context &c, whisper_full_params params, const float *samples, int n_sam
                     for (const auto &bc : bc_per_dec) beam_candidates.insert(beam_candidates.end(), bc.begin(), bc.end());
                     std::sort(beam_candidates.begin(), beam_candidates.end(),
                               [](const beam_candidate &a, const beam_candidate &b) {
-                                  return a.sequence.sum_logprobs_all > b.sequence.sum_logprobs_all;
+                                  return a.sum_logprobs_all > b.sum_logprobs_all;
                               });
+                    for (int j = 0; j < n_decoders_cur; ++j)  // the sources: every live decoder is overwritten below
+                        if (!(c.decoders[j].completed || c.decoders[j].failed)) old_seq[j] = std::move(c.decoders[j].sequence);
+                    auto same_tokens = [&](const beam_candidate &a, const beam_candidate &b) {
+                        return a.tk.id == b.tk.id && seq_tokens_equal(old_seq[a.decoder_idx], old_seq[b.decoder_idx]);
+                    };
                     uint32_t cur_c = 0;
                     for (int j = 0; j < n_decoders_cur; ++j) {
                         Decoder &d = c.decoders[j];
                         if (d.completed || d.failed) continue;
                         if (cur_c >= beam_candidates.size()) cur_c = 0;
                         auto &cur = beam_candidates[cur_c++];
-                        while (beam_candidates.size() > cur_c &&
-                               seq_tokens_equal(beam_candidates[cur_c].sequence, cur.sequence) && i > 0)
-                            ++cur_c;
+                        while (beam_candidates.size() > cur_c && same_tokens(beam_candidates[cur_c], cur) && i > 0) ++cur_c;
                         d.seek_delta = cur.seek_delta;
                         d.has_ts = cur.has_ts;
-                        d.sequence = cur.sequence;
+                        d.sequence = old_seq[cur.decoder_idx];
+                        d.sequence.tokens.push_back(cur.tk);
+                        d.sequence.sum_logprobs_all = cur.sum_logprobs_all;
                         src[j] = cur.decoder_idx;
                     }
                 } else {

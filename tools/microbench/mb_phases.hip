@@ -62,6 +62,20 @@ __global__ __launch_bounds__(MEGA_THREADS) void proj_probe_res(Proj p, const bf1
         for (int k = 0; k < 6; ++k) stamps[(size_t)blockIdx.x * NST + k] = s[k];
 }
 
+// warms the cache levels with the weights of the next projection: workgroup b reads the rows workgroup b of the
+// consumer will read (same blockIdx -> same XCD, if the dispatcher's round-robin holds), `mode` 2 reads them rotated
+// by one workgroup (lands in another XCD's L2: memory-side cache only)
+__global__ __launch_bounds__(512) void prefetch_rows(const bf16_t *W, long tile_elems, int mode, float *sink) {
+    const int b = mode == 2 ? (blockIdx.x + 1) % gridDim.x : blockIdx.x;
+    const uint4 *src = reinterpret_cast<const uint4 *>(W + (long)b * tile_elems);
+    unsigned acc = 0;
+    for (long i = threadIdx.x; i < tile_elems / 8; i += 512) {
+        const uint4 v = src[i];
+        acc += v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (acc == 0x12345u) sink[0] = 1.0f;
+}
+
 __global__ void producer(float *x, int cnt, float v, unsigned long long *t) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < cnt) x[i] = v + 0.001f * (float)(i % 97);
@@ -158,6 +172,12 @@ int main() {
         for (int it = 0; it < iters + 10; ++it) {
             if (it == 10) hipEventRecord(e0, st);
             Proj p{W + (size_t)(it % NBUF) * wmax, bias, c.N, c.K, 0};
+#ifdef PREFETCH
+            if (c.lean) {
+                const int fr = (!c.ln && c.K > 1280) ? 8 : 16;
+                hipLaunchKernelGGL(prefetch_rows, dim3(c.N / fr), dim3(512), 0, st, p.W, (long)fr * c.K, PREFETCH, outf + 4096);
+            }
+#endif
             if (c.ln) {
                 hipLaunchKernelGGL(producer, dim3((n * c.K + 255) / 256), dim3(256), 0, st, x, n * c.K, (float)it, tprod);
                 if (c.lean && c.epi == EPI_GELU_BF16)
