@@ -103,14 +103,23 @@ __global__ __launch_bounds__(PT) void logits_rules_kernel(const float *__restric
     const bool initial = S.n_sampled == 0;
     const int ts_lo = S.has_ts ? beg + S.seek_delta / 2 : beg;                       // timestamps below are suppressed
     const int ts_hi = (initial && P.tid0_initial >= 0) ? beg + P.tid0_initial : nv;  // timestamps above are suppressed
+    // every load first, unconditional (clamped index): a load under `if (i < s1)` is a branch and a wait per element
+    float lv[PV];
+    unsigned char sv[PV];
+#pragma unroll
+    for (int k = 0; k < PV; ++k) {
+        const int i = min(V.s0 + tid + k * PT, nv - 1);
+        lv[k] = V.lg[i];
+        sv[k] = suppress[i];
+    }
     float mx = -INFINITY, mx_text = -INFINITY, mx_ts = -INFINITY;
 #pragma unroll
     for (int k = 0; k < PV; ++k) {
         const int i = V.s0 + tid + k * PT;
         if (i < V.s1) {
-            float v = V.lg[i];
+            float v = lv[k];
             if (P.temperature > 0.0f) v /= P.temperature;
-            bool kill = suppress[i] != 0;
+            bool kill = sv[k] != 0;
             if (P.suppress_blank && initial && (i == P.eot || i == P.space_id)) kill = true;
             if (S.last_is_ts) {
                 if (S.penult_is_ts) kill |= i >= beg;
@@ -141,6 +150,15 @@ __global__ __launch_bounds__(PT) void logits_rules_kernel(const float *__restric
     }
 }
 
+// the row's PG records -> LDS with one 16-byte load per thread of wave 0.  Folding them straight from global
+// memory compiles to ~40 dependent scalar loads (one round trip each): 8-10 us of a 15 us kernel.
+__device__ __forceinline__ const SlabRec *stage_records(const SlabRec *rec, SlabRec *lds_rec) {
+    static_assert(PG * sizeof(SlabRec) == 64 * sizeof(uint4), "one uint4 per lane of one wave");
+    if (threadIdx.x < 64) reinterpret_cast<uint4 *>(lds_rec)[threadIdx.x] = reinterpret_cast<const uint4 *>(rec)[threadIdx.x];
+    __syncthreads();
+    return lds_rec;
+}
+
 __device__ __forceinline__ float row_max(const SlabRec *rec) {
     float m = rec[0].mx;
     for (int g = 1; g < PG; ++g) m = fmaxf(m, rec[g].mx);
@@ -163,9 +181,11 @@ __global__ __launch_bounds__(PT) void logits_sumexp_kernel(const float *__restri
 #pragma unroll
     for (int k = 0; k < PV; ++k) {
         const int i = V.s0 + tid + k * PT;
-        val[k] = i < V.s1 ? V.wk[i] : -INFINITY;
+        const float t = V.wk[min(i, P.n_vocab - 1)];  // unconditional load, selected afterwards
+        val[k] = i < V.s1 ? t : -INFINITY;
     }
-    const float mx = row_max(V.rec);
+    __shared__ SlabRec srec[PG];
+    const float mx = row_max(stage_records(V.rec, srec));
     float se = 0.0f;
 #pragma unroll
     for (int k = 0; k < PV; ++k)
@@ -193,12 +213,15 @@ __global__ __launch_bounds__(PT) void logits_stats_kernel(const float *__restric
 #pragma unroll
     for (int k = 0; k < PV; ++k) {
         const int i = V.s0 + tid + k * PT;
-        val[k] = i < V.s1 ? V.wk[i] : -INFINITY;
+        const float t = V.wk[min(i, P.n_vocab - 1)];  // unconditional load, selected afterwards
+        val[k] = i < V.s1 ? t : -INFINITY;
     }
-    const float mx = row_max(V.rec);
-    const float lse = row_lse(V.rec, mx);
-    float mx_ts = V.rec[0].mx_ts;
-    for (int g = 1; g < PG; ++g) mx_ts = fmaxf(mx_ts, V.rec[g].mx_ts);
+    __shared__ SlabRec srec[PG];
+    const SlabRec *rec = stage_records(V.rec, srec);
+    const float mx = row_max(rec);
+    const float lse = row_lse(rec, mx);
+    float mx_ts = rec[0].mx_ts;
+    for (int g = 1; g < PG; ++g) mx_ts = fmaxf(mx_ts, rec[g].mx_ts);
     const float lp_ts_max = mx_ts > -INFINITY ? mx_ts - lse : -INFINITY;
     float st = 0.0f, best_p = 0.0f, best_lp = 0.0f, best_tp = 0.0f, best_tlp = 0.0f;
     int best_i = -1, best_ti = -1;
@@ -281,7 +304,8 @@ __global__ __launch_bounds__(PT) void logits_sample_kernel(const float *__restri
     const int tid = threadIdx.x, r = blockIdx.y, g = blockIdx.x, nv = P.n_vocab, beg = P.beg;
     const LogitsRowState S = rows[r];
     const RowView V = row_view(logits, ld, work, S, nv);
-    const SlabRec *rec = V.rec;
+    __shared__ SlabRec srec[PG];
+    const SlabRec *rec = stage_records(V.rec, srec);
     // fold the row's records in slab order (every workgroup of the row computes the same values)
     const float mx = row_max(rec);
     const float lse = row_lse(rec, mx);
@@ -351,13 +375,19 @@ __global__ __launch_bounds__(PT) void logits_sample_kernel(const float *__restri
     }
     if (!any) return;  // uniform over the workgroup
     // thread t owns a contiguous chunk of the slab
-    const int sl = V.s1 - V.s0, ch = (sl + PT - 1) / PT;
+    const int sl = V.s1 - V.s0, ch = (sl + PT - 1) / PT;  // <= PV (checked at launch)
     const int i0 = min(V.s1, V.s0 + tid * ch), i1 = min(V.s1, i0 + ch);
-    double local = 0.0;
-    for (int i = i0; i < i1; ++i) {
-        const float v = V.wk[i];
-        if (v > -INFINITY && !(force_ts && i < beg)) local += (double)expf(v - lse) / total;
+    float cv[PV];  // the chunk's masked logits, loaded in one batch (a load per loop iteration is a round trip each)
+#pragma unroll
+    for (int k = 0; k < PV; ++k) {
+        const int i = i0 + k;
+        const float t = V.wk[min(i, nv - 1)];
+        cv[k] = (i < i1 && !(force_ts && i < beg)) ? t : -INFINITY;
     }
+    double local = 0.0;
+#pragma unroll
+    for (int k = 0; k < PV; ++k)
+        if (cv[k] > -INFINITY) local += (double)expf(cv[k] - lse) / total;
     double incl = local;
     for (int o = 1; o < 64; o <<= 1) {
         const double t = __shfl_up(incl, o);
@@ -379,20 +409,27 @@ __global__ __launch_bounds__(PT) void logits_sample_kernel(const float *__restri
         if (mine && i0 < i1) {
             double c = excl;
             int pick = -1, lastpos = -1;
-            for (int i = i0; i < i1; ++i) {
-                const float v = V.wk[i];
-                if (v > -INFINITY && !(force_ts && i < beg)) {
-                    c += (double)expf(v - lse) / total;
-                    lastpos = i;
-                }
-                if (c >= u) {
-                    pick = i;
-                    break;
+            float vp = -INFINITY, vlast = -INFINITY;  // masked logit of the pick / of the last live entry
+#pragma unroll
+            for (int k = 0; k < PV; ++k) {
+                const int i = i0 + k;
+                if (i < i1 && pick < 0) {
+                    if (cv[k] > -INFINITY) {
+                        c += (double)expf(cv[k] - lse) / total;
+                        lastpos = i;
+                        vlast = cv[k];
+                    }
+                    if (c >= u) {
+                        pick = i;
+                        vp = cv[k];
+                    }
                 }
             }
-            if (pick < 0) pick = lastpos >= 0 ? lastpos : i1 - 1;
-            float v = V.wk[pick];
-            if (force_ts && pick < beg) v = -INFINITY;
+            if (pick < 0) {
+                pick = lastpos >= 0 ? lastpos : i1 - 1;
+                vp = lastpos >= 0 ? vlast : -INFINITY;
+            }
+            const float v = vp;
             out->id[s] = pick;
             out->plog[s] = v > -INFINITY ? v - lse : -INFINITY;
             out->p[s] = v > -INFINITY ? expf(v - lse) : 0.0f;
