@@ -384,10 +384,12 @@ __global__ __launch_bounds__(PT) void logits_sample_kernel(const float *__restri
         const float t = V.wk[min(i, nv - 1)];
         cv[k] = (i < i1 && !(force_ts && i < beg)) ? t : -INFINITY;
     }
-    double local = 0.0;
+    double pk[PV], local = 0.0;  // normalised probabilities of the chunk: computed once, reused by every draw below
 #pragma unroll
-    for (int k = 0; k < PV; ++k)
-        if (cv[k] > -INFINITY) local += (double)expf(cv[k] - lse) / total;
+    for (int k = 0; k < PV; ++k) {
+        pk[k] = cv[k] > -INFINITY ? (double)expf(cv[k] - lse) / total : 0.0;
+        if (cv[k] > -INFINITY) local += pk[k];
+    }
     double incl = local;
     for (int o = 1; o < 64; o <<= 1) {
         const double t = __shfl_up(incl, o);
@@ -415,7 +417,7 @@ __global__ __launch_bounds__(PT) void logits_sample_kernel(const float *__restri
                 const int i = i0 + k;
                 if (i < i1 && pick < 0) {
                     if (cv[k] > -INFINITY) {
-                        c += (double)expf(cv[k] - lse) / total;
+                        c += pk[k];
                         lastpos = i;
                         vlast = cv[k];
                     }
