@@ -134,6 +134,7 @@ std::unique_ptr<Context> create_context(const unsigned char *data, size_t size, 
         c->wg_attn = true;
         c->proj_wg = hp.n_text_state % 128 == 0 && hp.n_text_state <= 1280 && !c->mfma_proj && getenv("MI355_WHISPER_NO_PROJ_WG") == nullptr;
         // residual classes (attention outputs, fc2) on matrix-core tiles too: K = 8 waves x {1,4} chunks x 2..5 steps x 32
+        c->logits_tile = getenv("MI355_WHISPER_NO_LOGITS_TILE") == nullptr;
         c->res_tile = c->proj_wg && hp.n_text_state % 256 == 0 && hp.n_text_state >= 512 && getenv("MI355_WHISPER_NO_RES_TILE") == nullptr;
     }
     // Measured slower than the graph-replayed step (cross-XCD hand-offs cost as much as a launch), so the
@@ -422,7 +423,8 @@ void decode(Context &c, const int *tokens, const int *pos, const int *slot, int 
             // LayerNorm-fused classes (qkv, cross-q, fc1) at <= 5 rows: one 16-feature tile per workgroup on the
             // matrix cores, LayerNorm per wave (mega.hip); the residual classes stay on the VALU stream kernels,
             // which spread their weight rows over 4x more workgroups (profiles/r01_*)
-            if (c.proj_wg && n <= 5 && (g.ln_w || res_tile) && g.tag != GEMV_LOGITS) launch_proj_wg(g, st);
+            if (c.proj_wg && c.logits_tile && g.tag == GEMV_LOGITS && logits_tile_supported(g)) launch_logits_tile(g, st);
+            else if (c.proj_wg && n <= 5 && (g.ln_w || res_tile) && g.tag != GEMV_LOGITS) launch_proj_wg(g, st);
             else if (c.mfma_proj && g.tag != GEMV_LOGITS) launch_gemv_mfma(g, st);  // matrix-core variant (dec_mfma.hip), opt-in
             else launch_gemv(g, wt, st);      // VALU weight-streaming path (dec.hip)
             if (prof) MW_HIP(hipEventRecord(c.prof_ev[c.prof_n++], st));

@@ -95,6 +95,7 @@ struct Context {
     bool mfma_proj = false;  // decode projections on MFMA (bf16 weights only; env MI355_WHISPER_MFMA_PROJ)
     std::unordered_map<uint64_t, hipGraphExec_t> graphs;
     bool proj_wg = false;            // tile-per-workgroup MFMA projections for <= 5 rows (env MI355_WHISPER_PROJ_WG)
+    bool logits_tile = false;        // logits projection on matrix-core tiles (bf16 weights, <= 5 rows)
     bool res_tile = false;           // residual-class projections on matrix-core tiles too (bf16 rows between the kernels)
     bool wg_attn = false;            // workgroup-wide attention kernels for <= 5 rows (bf16 K/V)
     unsigned *d_head_cnt = nullptr;  // per-head arrival counters of the fused cross-attention combine

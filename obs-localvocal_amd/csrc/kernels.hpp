@@ -190,6 +190,9 @@ struct MegaArgs {
 // workgroup-wide attention kernels for the <= 5-row step (bf16 K/V): every load of a (row, head) or (head, split)
 // item is issued up front; the cross kernel's last split per head combines the partial softmaxes itself
 // (head_cnt: H zeroed counters, left zeroed)
+// logits projection (final LayerNorm + tied embedding) on matrix-core tiles: bf16 weights, <= 5 gathered rows
+bool logits_tile_supported(const GemvArgs &a);
+void launch_logits_tile(const GemvArgs &a, hipStream_t st);
 void launch_self_attn_wg(const float *q, const void *kcache, const void *vcache, const int *d_slot, const int *d_pos,
                          const int *d_kv_idx, void *out, DType out_t, int n, int H, int d, int n_text_ctx, hipStream_t st);
 void launch_cross_attn_wg(const float *q, const void *kc, const void *vc, float *partial, void *out, DType out_t, unsigned *head_cnt,

@@ -663,6 +663,99 @@ __device__ __forceinline__ void self_attn_phase(const float *q, const bf16_t *kc
     }
 }
 
+// ---- the logits projection (final LayerNorm + tied token embedding, N = n_vocab) as tile kernel ----
+// 128 vocabulary rows per workgroup: the LayerNorm of the <= 5 sampled rows is done once (wave w = row w) and
+// shared through LDS; wave w then owns the 16-feature tile w over the whole K and needs nobody else's sums (no
+// cross-wave reduction).  Its weights stream in chunks of 128 k (16 rows x 256 contiguous bytes per chunk, 4 loads
+// per lane) through a ring of LRING chunks in registers and a wave-private LDS tile (fragment layout).
+constexpr int LKC = 128, LLD = LKC + 8, LRING = 3;
+
+template <int NB, int NCH>
+__device__ __forceinline__ void logits_tile(const bf16_t *W, const float *xin, const int *d_rows, const float *ln_w, const float *ln_b,
+                                            float *out, long ldo, int n, int N, bf16_t *xs, bf16_t *wtile) {
+    constexpr int K = NCH * LKC, nf4 = K / 4, ldxs = K + 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+    const int f0 = (blockIdx.x * 8 + wave) * 16;  // first vocabulary row of the wave's tile
+    // ---- loads: the wave's LayerNorm row (or one address), then the first LRING weight chunks ----
+    const bool has_row = wave < n;
+    const float *xr = xin + (long)d_rows[has_row ? wave : 0] * K;
+    float4 v[LN_MAX_F4], gw[LN_MAX_F4], gb[LN_MAX_F4];
+#pragma unroll
+    for (int i = 0; i < LN_MAX_F4; ++i) v[i] = *reinterpret_cast<const float4 *>(xr + (has_row ? 4 * min(lane + 64 * i, nf4 - 1) : 0));
+#pragma unroll
+    for (int i = 0; i < LN_MAX_F4; ++i) {
+        const int c = has_row ? 4 * min(lane + 64 * i, nf4 - 1) : 0;
+        gw[i] = *reinterpret_cast<const float4 *>(ln_w + c);
+        gb[i] = *reinterpret_cast<const float4 *>(ln_b + c);
+    }
+    // weight piece (chunk c, load j): row = (lane + 64 j) >> 4, 16-byte column = (lane + 64 j) & 15
+    const bf16_t *wl[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int pc = lane + 64 * j;
+        wl[j] = W + (long)min(f0 + (pc >> 4), N - 1) * K + 8 * (pc & 15);  // rows beyond the vocabulary: clamped, never stored
+    }
+    uint4 w[NCH][4];
+#pragma unroll
+    for (int c = 0; c < LRING && c < NCH; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[c][j] = ld_stream16(wl[j] + c * LKC);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- LayerNorm of the wave's row -> bf16 in LDS ----
+    {
+        float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < LN_MAX_F4; ++i) s += lane + 64 * i < nf4 ? (v[i].x + v[i].y) + (v[i].z + v[i].w) : 0.0f;
+        const float mean = wave_total(s) * (1.0f / (float)K);
+        float q = 0.0f;
+#pragma unroll
+        for (int i = 0; i < LN_MAX_F4; ++i) {
+            const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
+            q += lane + 64 * i < nf4 ? (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3) : 0.0f;
+        }
+        const float rstd = rsqrtf(wave_total(q) * (1.0f / (float)K) + 1e-5f);
+#pragma unroll
+        for (int i = 0; i < LN_MAX_F4; ++i) {
+            const int c = lane + 64 * i;
+            const float y0 = (v[i].x - mean) * rstd * gw[i].x + gb[i].x, y1 = (v[i].y - mean) * rstd * gw[i].y + gb[i].y;
+            const float y2 = (v[i].z - mean) * rstd * gw[i].z + gb[i].z, y3 = (v[i].w - mean) * rstd * gw[i].w + gb[i].w;
+            uint2 pk;
+            pk.x = (unsigned)to_bf16(y0) | ((unsigned)to_bf16(y1) << 16);
+            pk.y = (unsigned)to_bf16(y2) | ((unsigned)to_bf16(y3) << 16);
+            if (c < nf4 && wave < n) *reinterpret_cast<uint2 *>(xs + wave * ldxs + 4 * c) = pk;
+        }
+    }
+    lds_sync();
+    // ---- the wave's tile over all of K: chunk c from the ring -> private LDS tile -> 4 MFMA steps ----
+    bf16_t *wt = wtile + wave * 16 * LLD;
+    const bf16_t *arow = xs + (fr < n ? fr : 0) * ldxs + 8 * fq;
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int pc = lane + 64 * j;
+            *reinterpret_cast<uint4 *>(wt + (pc >> 4) * LLD + 8 * (pc & 15)) = w[c][j];
+        }
+        if (c + LRING < NCH) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[c + LRING][j] = ld_stream16(wl[j] + (c + LRING) * LKC);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+            const uint4 af = *reinterpret_cast<const uint4 *>(arow + c * LKC + 32 * s2);
+            const uint4 bfr = *reinterpret_cast<const uint4 *>(wt + fr * LLD + 32 * s2 + 8 * fq);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8b, af), __builtin_bit_cast(bf16x8b, bfr), acc, 0, 0, 0);
+        }
+    }
+    // lane holds rows 4*fq + r of vocabulary entry f0 + fr
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * fq + r;
+        if (row < n && f0 + fr < N) out[(long)row * ldo + f0 + fr] = acc[r];
+    }
+}
+
 // ---- self-attention as a kernel of its own, straight-line: three dependent load levels and no more ----
 //   1. pos / slot of the row (scalar) and the thread's 8 query values        2. the index-table entries of its keys
 //   3. its 16-byte K and V chunks (thread (jj, e8): keys jj, jj+64, ...; 8 lanes cover a 128-byte head row, so an
@@ -1286,6 +1379,14 @@ __global__ __launch_bounds__(MEGA_THREADS) void self_attn_wg_kernel(const float 
     self_attn_phase<OT>(q, kc, vc, slot, pos, kv_idx, out, n, H, d, TC, lds);
 }
 
+template <int NB, int NCH>
+__global__ __launch_bounds__(MEGA_THREADS) void logits_tile_kernel(const bf16_t *W, const float *xin, const int *d_rows, const float *ln_w,
+                                                                    const float *ln_b, float *out, long ldo, int n, int N) {
+    __shared__ __attribute__((aligned(16))) bf16_t xs[NB * (NCH * LKC + 8)];
+    __shared__ __attribute__((aligned(16))) bf16_t wtile[8 * 16 * LLD];
+    logits_tile<NB, NCH>(W, xin, d_rows, ln_w, ln_b, out, ldo, n, N, xs, wtile);
+}
+
 template <typename OT>
 __global__ __launch_bounds__(MEGA_THREADS) void self_attn_lean_kernel(const float *q, const bf16_t *kc, const bf16_t *vc, const int *slot,
                                                                        const int *pos, const int *kv_idx, OT *out, int H, int d, int TC) {
@@ -1436,6 +1537,35 @@ void launch_proj_wg(const GemvArgs &a, hipStream_t st) {
 #undef MW_PROJ_NB
 #undef MW_PROJ_LN
 #undef MW_PROJ
+    MW_HIP(hipGetLastError());
+}
+
+bool logits_tile_supported(const GemvArgs &a) {
+    const int nch = a.K / LKC;
+    return a.n >= 1 && a.n <= 5 && a.ln_w && a.ln_b && a.d_rows && a.K % LKC == 0 && a.ldx == a.K && !a.bias && !a.R &&
+           a.act == ACT_NONE && a.out_scale == 1.0f && (nch == 3 || nch == 4 || nch == 6 || nch == 8 || nch == 10);
+}
+
+void launch_logits_tile(const GemvArgs &a, hipStream_t st) {
+    MW_CHECK(logits_tile_supported(a), "logits_tile: shape");
+    const dim3 grid(ceil_div(a.N, 128)), block(MT);
+#define MW_LT(NBv, NCHv)                                                                                                     \
+    hipLaunchKernelGGL((logits_tile_kernel<NBv, NCHv>), grid, block, 0, st, (const bf16_t *)a.W, a.x, a.d_rows, a.ln_w, a.ln_b, \
+                       a.out, a.ldo, a.n, a.N)
+#define MW_LT_NB(NCHv)              \
+    do {                             \
+        if (a.n == 1) MW_LT(1, NCHv); \
+        else MW_LT(5, NCHv);          \
+    } while (0)
+    switch (a.K / LKC) {
+    case 3: MW_LT_NB(3); break;
+    case 4: MW_LT_NB(4); break;
+    case 6: MW_LT_NB(6); break;
+    case 8: MW_LT_NB(8); break;
+    default: MW_LT_NB(10); break;
+    }
+#undef MW_LT_NB
+#undef MW_LT
     MW_HIP(hipGetLastError());
 }
 
