@@ -1,0 +1,187 @@
+// enc_attn.hip — fused encoder self-attention (bf16): softmax(Q K^T / sqrt(dh)) V per head without the score matrix
+// ever leaving the chip.
+//
+// Replaces, for the bf16 mode, the unfused sequence of whisper.cpp's encoder graph (mul_mat KQ -> soft_max -> mul_mat
+// KQV) that moved ~370 MB per layer (fp32 scores written and re-read, bf16 probabilities written and
+// re-read).  Bound: MFMA / exp throughput (11.8 GFLOP per layer at n_ctx 1500).
+//
+// One 256-thread workgroup per (128 queries, head); wave w owns 32 queries (two 16-query tiles).  Keys go by in steps
+// of 64: the K rows [key][dim] and the V^T rows [dim][key] (the V projection already stores V transposed) are
+// double-buffered through LDS with coalesced 128-byte rows.  Everything is computed transposed so that no operand
+// ever changes lanes:
+//   S^T[key][query] = K . Q^T       A = K tile (lane: key l&15, 8 dims), B = Q (lane: query l&15, 8 dims; registers)
+//                                   -> lane (q = l&15, g = l>>4) holds keys 4g..4g+3 of each 16-key tile
+//   O^T[dim][query] += V^T . P^T    B = P^T needs 8 contraction entries per lane: the lane's 4+4 probabilities of two
+//                                   key tiles ARE such a fragment if the contraction index of the 32-key chunk is
+//                                   ordered (g, tile, r); the V^T fragment is read from LDS in the same order (two
+//                                   8-byte reads).  The running maximum / sum of a query live in the lanes that hold
+//                                   its column (l&15), replicated over g; the sum is completed across g at the end.
+#include "kernels.hpp"
+
+namespace mw {
+
+namespace {
+
+using bf16x8b = __attribute__((ext_vector_type(8))) __bf16;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int FQ = 128;      // queries per workgroup
+constexpr int FK = 64;       // keys per step
+constexpr int FLD = 64 + 8;  // LDS row stride (elements): conflict-free 16-byte fragment reads
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    // round to nearest even, like the conversions of the unfused path
+    unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+    ua += 0x7fffu + ((ua >> 16) & 1u);
+    ub += 0x7fffu + ((ub >> 16) & 1u);
+    return (ua >> 16) | (ub & 0xffff0000u);
+}
+
+__global__ __launch_bounds__(256) void enc_flash_attn_kernel(const bf16_t *__restrict__ qk, const bf16_t *__restrict__ vt,
+                                                             bf16_t *__restrict__ out, int n_ctx, int tp, int d, float scale_log2) {
+    __shared__ __attribute__((aligned(16))) bf16_t kt[2][FK * FLD];
+    __shared__ __attribute__((aligned(16))) bf16_t vs[2][64 * FLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+    const int h = blockIdx.y, q0 = blockIdx.x * FQ + wave * 32;
+    const long ldq = 2L * d;
+    // Q fragments of the wave's two query tiles (loop invariant)
+    uint4 qf[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            qf[i][s] = *reinterpret_cast<const uint4 *>(qk + (long)min(q0 + 16 * i + fr, n_ctx - 1) * ldq + h * 64 + 32 * s + 8 * fq);
+    // tile loader: thread -> row tid>>2 (a key of K / a dim of V^T), 32 bytes at element (tid&3)*16
+    const int lrow = tid >> 2, lcol = (tid & 3) * 16;
+    uint4 rk[2], rv[2];
+    auto gload = [&](int step) {
+        const bf16_t *kp = qk + (long)min(step * FK + lrow, n_ctx - 1) * ldq + d + h * 64 + lcol;
+        const bf16_t *vp = vt + (long)(h * 64 + lrow) * tp + step * FK + lcol;
+        rk[0] = *reinterpret_cast<const uint4 *>(kp);
+        rk[1] = *reinterpret_cast<const uint4 *>(kp + 8);
+        rv[0] = *reinterpret_cast<const uint4 *>(vp);
+        rv[1] = *reinterpret_cast<const uint4 *>(vp + 8);
+    };
+    auto lstore = [&](int buf) {
+        *reinterpret_cast<uint4 *>(&kt[buf][lrow * FLD + lcol]) = rk[0];
+        *reinterpret_cast<uint4 *>(&kt[buf][lrow * FLD + lcol + 8]) = rk[1];
+        *reinterpret_cast<uint4 *>(&vs[buf][lrow * FLD + lcol]) = rv[0];
+        *reinterpret_cast<uint4 *>(&vs[buf][lrow * FLD + lcol + 8]) = rv[1];
+    };
+    f32x4 o[2][4];
+    float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) o[i][t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    const int nsteps = tp / FK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int step = 0; step < nsteps; ++step) {
+        const int cur = step & 1;
+        if (step + 1 < nsteps) gload(step + 1);
+        const bf16_t *kb = kt[cur], *vb = vs[cur];
+        // ---- S^T tiles ----
+        f32x4 sa[2][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint4 a0 = *reinterpret_cast<const uint4 *>(kb + (16 * t + fr) * FLD + 8 * fq);
+            const uint4 a1 = *reinterpret_cast<const uint4 *>(kb + (16 * t + fr) * FLD + 32 + 8 * fq);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8b, a0), __builtin_bit_cast(bf16x8b, qf[i][0]), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8b, a1), __builtin_bit_cast(bf16x8b, qf[i][1]), acc, 0, 0, 0);
+                sa[i][t] = acc;
+            }
+        }
+        // ---- online softmax (base 2), probabilities as P^T fragments ----
+        uint4 pb[2][2];
+        const int key_base = step * FK + 4 * fq;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float mx = m[i];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = sa[i][t][r] * scale_log2;
+                    if (key_base + 16 * t + r >= n_ctx) v = -INFINITY;
+                    sa[i][t][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float corr = __builtin_amdgcn_exp2f(m[i] - mx);  // first step: exp2(-inf) = 0
+            m[i] = mx;
+            float ps = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(sa[i][t][r] - mx);
+                    sa[i][t][r] = p;
+                    ps += p;
+                }
+            l[i] = l[i] * corr + ps;  // this lane's share (its 16 keys of the step); completed across g at the end
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[i][t][r] *= corr;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                pb[i][c].x = pack_bf16(sa[i][2 * c][0], sa[i][2 * c][1]);
+                pb[i][c].y = pack_bf16(sa[i][2 * c][2], sa[i][2 * c][3]);
+                pb[i][c].z = pack_bf16(sa[i][2 * c + 1][0], sa[i][2 * c + 1][1]);
+                pb[i][c].w = pack_bf16(sa[i][2 * c + 1][2], sa[i][2 * c + 1][3]);
+            }
+        }
+        // ---- O^T += V^T . P^T ----
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const uint2 v0 = *reinterpret_cast<const uint2 *>(vb + (16 * t + fr) * FLD + 32 * c + 4 * fq);
+                const uint2 v1 = *reinterpret_cast<const uint2 *>(vb + (16 * t + fr) * FLD + 32 * c + 16 + 4 * fq);
+                const uint4 af = make_uint4(v0.x, v0.y, v1.x, v1.y);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    o[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8b, af), __builtin_bit_cast(bf16x8b, pb[i][c]),
+                                                                      o[i][t], 0, 0, 0);
+            }
+        if (step + 1 < nsteps) {
+            lstore(cur ^ 1);  // the other buffer was last read before the previous barrier
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        float ls = l[i];
+        ls += __shfl_xor(ls, 16);
+        ls += __shfl_xor(ls, 32);
+        const float inv = 1.0f / ls;
+        const int q = q0 + 16 * i + fr;
+        if (q < n_ctx) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                uint2 pk;
+                pk.x = pack_bf16(o[i][t][0] * inv, o[i][t][1] * inv);
+                pk.y = pack_bf16(o[i][t][2] * inv, o[i][t][3] * inv);
+                *reinterpret_cast<uint2 *>(out + (long)q * d + h * 64 + 16 * t + 4 * fq) = pk;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+void launch_enc_flash_attn(const void *qk, const void *vt, void *out, int n_ctx, int tp, int d, int H, hipStream_t st) {
+    MW_CHECK(qk && vt && out && n_ctx > 0 && d == H * 64 && tp % FK == 0 && tp >= n_ctx && tp - n_ctx < FK, "enc_flash_attn: shape");
+    const float scale_log2 = (1.0f / sqrtf(64.0f)) * 1.4426950408889634f;
+    hipLaunchKernelGGL(enc_flash_attn_kernel, dim3(ceil_div(n_ctx, FQ), H), dim3(256), 0, st, (const bf16_t *)qk, (const bf16_t *)vt,
+                       (bf16_t *)out, n_ctx, tp, d, scale_log2);
+    MW_HIP(hipGetLastError());
+}
+
+}  // namespace mw

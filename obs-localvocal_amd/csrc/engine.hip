@@ -126,6 +126,7 @@ std::unique_ptr<Context> create_context(const unsigned char *data, size_t size, 
     if (getenv("MI355_WHISPER_NO_GRAPH")) c->use_graphs = false;  // debugging aid: eager launches
     // the matrix-core projection variant measured ~5 % slower per window than the VALU one at 5 rows
     // (profiles/r01_*): kept selectable for wider batches
+    c->flash_attn = wt == DType::BF16 && getenv("MI355_WHISPER_NO_FLASH_ATTN") == nullptr;
     c->mfma_proj = wt == DType::BF16 && getenv("MI355_WHISPER_MFMA_PROJ") != nullptr;
     // persistent decode kernel: the whole decoder stack of a <= 5-row step in one cooperative launch
     if (wt == DType::BF16 && TC <= (size_t)MEGA_TC_MAX && hp.n_text_state == hp.n_text_head * 64 && !getenv("MI355_WHISPER_NO_WG_ATTN")) {
@@ -271,20 +272,24 @@ void encode(Context &c, int seek) {
             g.M = n_ctx; g.N = d; g.K = d; g.trans_c = 1;
             launch_gemm(g, wt, wt, st);
         }
-        {
-            GemmArgs g;  // S_h = Q_h K_h^T, batched over heads
-            g.A = c.d_qk; g.lda = 2 * d; g.W = (char *)c.d_qk + (size_t)d * ws; g.ldw = 2 * d;
-            g.C = c.d_s; g.ldc = tp; g.M = n_ctx; g.N = n_ctx; g.K = 64;
-            g.nz1 = H; g.sA1 = 64; g.sW1 = 64; g.sC1 = (long)n_ctx * tp;
-            launch_gemm(g, wt, DType::F32, st);
-        }
-        launch_softmax_rows(c.d_s, tp, c.d_p, tp, wt, (long)H * n_ctx, n_ctx, tp, 1.0f / sqrtf(64.0f), st);
-        {
-            GemmArgs g;  // O_h = P_h V_h
-            g.A = c.d_p; g.lda = tp; g.W = c.d_vt; g.ldw = tp; g.C = c.d_att; g.ldc = d;
-            g.M = n_ctx; g.N = 64; g.K = tp;
-            g.nz1 = H; g.sA1 = (long)n_ctx * tp; g.sW1 = (long)64 * tp; g.sC1 = 64;
-            launch_gemm(g, wt, wt, st);
+        if (c.flash_attn) {
+            launch_enc_flash_attn(c.d_qk, c.d_vt, c.d_att, n_ctx, tp, d, H, st);  // fused: scores never leave the chip
+        } else {
+            {
+                GemmArgs g;  // S_h = Q_h K_h^T, batched over heads
+                g.A = c.d_qk; g.lda = 2 * d; g.W = (char *)c.d_qk + (size_t)d * ws; g.ldw = 2 * d;
+                g.C = c.d_s; g.ldc = tp; g.M = n_ctx; g.N = n_ctx; g.K = 64;
+                g.nz1 = H; g.sA1 = 64; g.sW1 = 64; g.sC1 = (long)n_ctx * tp;
+                launch_gemm(g, wt, DType::F32, st);
+            }
+            launch_softmax_rows(c.d_s, tp, c.d_p, tp, wt, (long)H * n_ctx, n_ctx, tp, 1.0f / sqrtf(64.0f), st);
+            {
+                GemmArgs g;  // O_h = P_h V_h
+                g.A = c.d_p; g.lda = tp; g.W = c.d_vt; g.ldw = tp; g.C = c.d_att; g.ldc = d;
+                g.M = n_ctx; g.N = 64; g.K = tp;
+                g.nz1 = H; g.sA1 = (long)n_ctx * tp; g.sW1 = (long)64 * tp; g.sC1 = 64;
+                launch_gemm(g, wt, wt, st);
+            }
         }
         {
             GemmArgs g;  // x += att Wo^T + bo

@@ -92,6 +92,7 @@ struct Context {
     std::vector<hipEvent_t> prof_ev;
     // captured decode steps, keyed by (rows, logits rows, audio ctx, index-table parity)
     bool use_graphs = true;
+    bool flash_attn = false;  // fused encoder attention (bf16 only; env MI355_WHISPER_NO_FLASH_ATTN)
     bool mfma_proj = false;  // decode projections on MFMA (bf16 weights only; env MI355_WHISPER_MFMA_PROJ)
     std::unordered_map<uint64_t, hipGraphExec_t> graphs;
     bool proj_wg = false;            // tile-per-workgroup MFMA projections for <= 5 rows (env MI355_WHISPER_PROJ_WG)
