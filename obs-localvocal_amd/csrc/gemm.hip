@@ -25,9 +25,9 @@ using bf16x8b = __attribute__((ext_vector_type(8))) __bf16;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-constexpr int BM = 128, BN = 128;
+constexpr int BN = 128;  // BM (128 or 64 rows) is a template parameter: 64 doubles the tiles of narrow-N shapes
 constexpr int ROW_BYTES = 64;  // K-extent of one LDS tile row: 32 bf16 or 16 f32
-constexpr int F32_LD = BM + 4; // k-major f32 tile: row length (floats) incl. padding
+constexpr int F32_LD = 128 + 4; // k-major f32 tile: row length (floats) incl. padding
 
 __device__ __forceinline__ float gelu_f(float x) {
     const float c = 0.79788456080286535587989211986876f, a = 0.044715f;
@@ -46,16 +46,19 @@ __device__ __forceinline__ int swz(int r, int c) {
     return r * ROW_BYTES + ((c ^ g) << 4);
 }
 
-template <typename TIN, typename TOUT>
+template <typename TIN, typename TOUT, int BM>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
     constexpr bool F32 = sizeof(TIN) == 4;
+    static_assert(BM == 128 || (BM == 64 && !F32), "64-row tiles: bf16 path only");
+    constexpr int WJ = BM == 128 ? 4 : 2;  // 16-column MFMA tiles per wave: waves are 2 x 2 (64 x 64 each) or 1 x 4 (64 x 32 each)
     constexpr int BK = ROW_BYTES / (int)sizeof(TIN);
     // LDS: [2 buffers][A | W]; bf16: 128 rows x 64 B swizzled; f32: 16 k-rows x F32_LD floats
-    constexpr int TILE_BYTES = F32 ? 16 * F32_LD * 4 : BM * ROW_BYTES;
+    constexpr int TILE_BYTES = F32 ? 16 * F32_LD * 4 : 128 * ROW_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * TILE_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = BM == 128 ? wave >> 1 : 0, wc = BM == 128 ? wave & 1 : wave;
+    constexpr int WCOLS = BM == 128 ? 64 : 32;  // columns per wave
     const int z0 = blockIdx.z / a.nz1, z1 = blockIdx.z % a.nz1;
     const TIN *A = (const TIN *)a.A + z0 * a.sA0 + z1 * a.sA1;
     const TIN *W = (const TIN *)a.W + z0 * a.sW0 + z1 * a.sW1;
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
         for (int q = 0; q < 2; ++q) {
             const int kk = kt * BK + lchk[q] * (16 / (int)sizeof(TIN));
             if (kk < K) {
-                ra_[q] = *reinterpret_cast<const uint4 *>(ga[q] + (long)kt * BK);
+                if (BM == 128 || q == 0) ra_[q] = *reinterpret_cast<const uint4 *>(ga[q] + (long)kt * BK);
                 rw_[q] = *reinterpret_cast<const uint4 *>(gw[q] + (long)kt * BK);
             } else {
                 ra_[q] = make_uint4(0, 0, 0, 0);
@@ -108,14 +111,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
                 fw[(kb + 2) * F32_LD + lrow[q]] = __uint_as_float(rw_[q].z);
                 fw[(kb + 3) * F32_LD + lrow[q]] = __uint_as_float(rw_[q].w);
             } else {
-                *reinterpret_cast<uint4 *>(la + swz(lrow[q], lchk[q])) = ra_[q];
+                if (BM == 128 || q == 0) *reinterpret_cast<uint4 *>(la + swz(lrow[q], lchk[q])) = ra_[q];
                 *reinterpret_cast<uint4 *>(lw + swz(lrow[q], lchk[q])) = rw_[q];
             }
         }
     };
 
     // accumulators: bf16 path 4x4 tiles of 16x16 (f32x4); fp32 path 2x2 tiles of 32x32 (f32x16)
-    f32x4 acc16[F32 ? 1 : 4][F32 ? 1 : 4];
+    f32x4 acc16[F32 ? 1 : 4][F32 ? 1 : WJ];
     f32x16 acc32[F32 ? 2 : 1][F32 ? 2 : 1];
     if constexpr (F32) {
 #pragma unroll
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc16[i][j] = f32x4{0, 0, 0, 0};
+            for (int j = 0; j < WJ; ++j) acc16[i][j] = f32x4{0, 0, 0, 0};
     }
 
     gload(0);
@@ -157,16 +160,15 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
             }
         } else {
             const int fr = lane & 15, fq = lane >> 4;
-            bf16x8 af[4], bfr[4];
+            bf16x8 af[4], bfr[WJ];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                af[i] = *reinterpret_cast<const bf16x8 *>(la + swz(wr * 64 + i * 16 + fr, fq));
-                bfr[i] = *reinterpret_cast<const bf16x8 *>(lw + swz(wc * 64 + i * 16 + fr, fq));
-            }
+            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8 *>(la + swz(wr * 64 + i * 16 + fr, fq));
+#pragma unroll
+            for (int j = 0; j < WJ; ++j) bfr[j] = *reinterpret_cast<const bf16x8 *>(lw + swz(wc * WCOLS + j * 16 + fr, fq));
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < WJ; ++j)
                     acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                         __builtin_bit_cast(bf16x8b, af[i]), __builtin_bit_cast(bf16x8b, bfr[j]), acc16[i][j], 0, 0, 0);
         }
@@ -200,10 +202,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < WJ; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    emit(m0 + wr * 64 + i * 16 + (lane >> 4) * 4 + r, n0 + wc * 64 + j * 16 + (lane & 15), acc16[i][j][r]);
+                    emit(m0 + wr * 64 + i * 16 + (lane >> 4) * 4 + r, n0 + wc * WCOLS + j * 16 + (lane & 15), acc16[i][j][r]);
     }
 }
 
@@ -220,14 +222,22 @@ void launch_gemm(const GemmArgs &a, DType in, DType out, hipStream_t st) {
     // note: lda < K is legal — the conv stem passes overlapping row views (row t = rows t-1..t+1)
     MW_CHECK(a.nz0 >= 1 && a.nz1 >= 1 && (long)a.nz0 * a.nz1 <= 65535, "gemm: batch count");
     if (a.R) MW_CHECK(a.ldr > 0, "gemm: residual stride");
-    dim3 grid(ceil_div(a.N, BN), ceil_div(a.M, BM), a.nz0 * a.nz1);
+    // 64-row tiles when 128-row tiles would leave most of the 256 CUs without a tile (N = d projections at M = 1500)
+    const long tiles128 = (long)ceil_div(a.N, BN) * ceil_div(a.M, 128) * a.nz0 * a.nz1;
+    static const bool no64 = getenv("MI355_WHISPER_GEMM_BM128") != nullptr;  // experiments: 128-row tiles only
+    const bool bm64 = in == DType::BF16 && tiles128 < 200 && a.M > 64 && !no64;
+    dim3 grid(ceil_div(a.N, BN), ceil_div(a.M, bm64 ? 64 : 128), a.nz0 * a.nz1);
     MW_CHECK(grid.y <= 65535, "gemm: M too large for grid.y");
     if (in == DType::F32 && out == DType::F32)
-        hipLaunchKernelGGL((gemm_nt_kernel<float, float>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((gemm_nt_kernel<float, float, 128>), grid, dim3(256), 0, st, a);
+    else if (in == DType::BF16 && out == DType::F32 && bm64)
+        hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, float, 64>), grid, dim3(256), 0, st, a);
     else if (in == DType::BF16 && out == DType::F32)
-        hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, float>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, float, 128>), grid, dim3(256), 0, st, a);
+    else if (in == DType::BF16 && out == DType::BF16 && bm64)
+        hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, bf16_t, 64>), grid, dim3(256), 0, st, a);
     else if (in == DType::BF16 && out == DType::BF16)
-        hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, bf16_t, 128>), grid, dim3(256), 0, st, a);
     else
         MW_CHECK(false, "gemm: unsupported dtype combination");
     MW_HIP(hipGetLastError());
