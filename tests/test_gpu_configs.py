@@ -100,3 +100,33 @@ def test_contexts_are_reentrant_across_threads(pkg, model_file):
         t.join()
     assert not errs, errs
     assert out == alone
+
+
+@pytest.mark.parametrize("width,heads", [(384, 6), (512, 8), (768, 12), (1024, 16), (1280, 20)])
+def test_tile_kernels_every_model_width_bf16(pkg, model_file, width, heads):
+    # The beam-step tile kernels are specialised per width (k-steps per wave, chunks per row, vocabulary chunks of the
+    # logits kernel); tiny/base/small/medium/large widths with 2 layers each, 5 rows at once (the beam-5 shape),
+    # bf16 logits against the fp32 oracle on the same file, stated tolerance as test_decoder_bf16_within_tolerance.
+    path = model_file("tiny.en", ftype=1, n_audio_state=width, n_audio_head=heads, n_audio_layer=2,
+                      n_text_state=width, n_text_head=heads, n_text_layer=2)
+    pcm = ggml_io.synth_pcm(3, 4.0)
+    orc = pyoracle.Oracle(path)
+    eng = pkg.Engine(path, precision=pkg.PRECISION_BF16)
+    try:
+        orc.mel(pcm)
+        eng.mel(pcm)
+        orc.encode(0)
+        eng.encode(0)
+        toks = [orc.sot, 11, 22, 33, 44]
+        ref, got = orc.decode(toks, 0, 0), eng.decode(toks, 0, 0)   # 5 rows in one call
+        assert got.shape == ref.shape
+        # bf16 operands: the error grows with the logits' scale (which grows with the width); 0.6 % of their spread (measured: 0.30-0.37 %)
+        tol = 0.006 * float(ref.max() - ref.min())
+        err = float(np.abs(got - ref).max())
+        print(f"width {width}: max |bf16 - fp32 oracle| = {err:.4f}, logits spread {ref.max() - ref.min():.2f}, tol {tol:.4f}")
+        assert err < tol
+        r1, g1 = orc.decode([55], 5, 0)[0], eng.decode([55], 5, 0)[0]   # single row (greedy shape)
+        assert np.abs(g1 - r1).max() < tol
+    finally:
+        eng.close()
+        orc.close()
