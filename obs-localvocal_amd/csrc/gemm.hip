@@ -209,6 +209,148 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
     }
 }
 
+// ---- bf16 path with 64-deep k-steps ----
+// Same tiling as gemm_nt_kernel<bf16> (128 or 64 x 128 tile, 4 waves, 16x16x32 MFMA) with twice the k-extent per
+// iteration: the loop is bound by the latency of the next tile's global loads (one barrier and one wait per
+// iteration), so halving the iterations nearly halves the time.  LDS rows are 128 bytes, 16-byte chunk c of row r
+// lives at chunk c ^ (r & 7); every load is unconditional (clamped address, zero selected afterwards).
+template <typename TOUT, int BM, bool TR>
+__global__ __launch_bounds__(256) void gemm_bf16_k64_kernel(GemmArgs a) {
+    constexpr int BK = 64, RB = 128, TILE = 128 * RB;
+    constexpr int WJ = BM == 128 ? 4 : 2, WCOLS = BM == 128 ? 64 : 32, QA = BM == 128 ? 4 : 2;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * TILE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = BM == 128 ? wave >> 1 : 0, wc = BM == 128 ? wave & 1 : wave;
+    const int z0 = blockIdx.z / a.nz1, z1 = blockIdx.z % a.nz1;
+    const bf16_t *A = (const bf16_t *)a.A + z0 * a.sA0 + z1 * a.sA1;
+    const bf16_t *W = (const bf16_t *)a.W + z0 * a.sW0 + z1 * a.sW1;
+    TOUT *C = (TOUT *)a.C + z0 * a.sC0 + z1 * a.sC1;
+    const float *bias = a.bias ? a.bias + z0 * a.sB0 + z1 * a.sB1 : nullptr;
+    const float *R = a.R ? a.R + z0 * a.sR0 + z1 * a.sR1 : nullptr;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int M = a.M, N = a.N, K = a.K;
+    auto swz8 = [](int r, int c) { return r * RB + ((c ^ (r & 7)) << 4); };
+    // this thread's 16-byte chunks: idx = tid + 256 q -> row idx >> 3, chunk idx & 7
+    const bf16_t *ga[QA], *gw[4];
+    int lo[4];  // LDS offset of chunk q (same for both operands)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int idx = tid + 256 * q, row = idx >> 3, chk = idx & 7;
+        lo[q] = swz8(row, chk);
+        if (q < QA) ga[q] = A + (long)min(m0 + row, M - 1) * a.lda + chk * 8;
+        gw[q] = W + (long)min(n0 + row, N - 1) * a.ldw + chk * 8;
+    }
+    const int kchk = (tid & 7) * 8;  // k offset of this thread's chunks inside a k-step
+    const int nk = (K + BK - 1) / BK;
+    // Register ring of NS k-steps: the loads of step kt + NS - 1 are issued while step kt is multiplied, so a load has
+    // NS - 2 iterations (not one) to arrive before its tile goes to LDS.  The k-loop is unrolled by NS so that every
+    // ring index is a constant; steps beyond nk reload the last tile (clamped) and store zeros: no branch in the loop.
+    constexpr int NS = 4;
+    uint4 ra[NS][QA], rw[NS][4];
+    auto gload = [&](int kt, uint4(&pa)[QA], uint4(&pw)[4]) {
+        const int kc = min(kt, nk - 1);
+        const bool ok = kt < nk && kc * BK + kchk < K;
+        const long off = kc * BK + kchk < K ? (long)kc * BK : 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (q < QA) {
+                const uint4 t = *reinterpret_cast<const uint4 *>(ga[q] + off);
+                pa[q] = ok ? t : make_uint4(0, 0, 0, 0);
+            }
+            const uint4 u = *reinterpret_cast<const uint4 *>(gw[q] + off);
+            pw[q] = ok ? u : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto lstore = [&](int buf, const uint4(&pa)[QA], const uint4(&pw)[4]) {
+        unsigned char *la = lds + buf * 2 * TILE, *lw = la + TILE;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (q < QA) *reinterpret_cast<uint4 *>(la + lo[q]) = pa[q];
+            *reinterpret_cast<uint4 *>(lw + lo[q]) = pw[q];
+        }
+    };
+    f32x4 acc[4][WJ];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < WJ; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int u = 0; u < NS - 1; ++u) gload(u, ra[u], rw[u]);
+    lstore(0, ra[0], rw[0]);
+    __syncthreads();
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int kt0 = 0; kt0 < nk; kt0 += NS) {
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            const int kt = kt0 + u, cur = u & 1;  // NS is even: the LDS buffer parity of step kt is that of u
+            gload(kt + NS - 1, ra[(u + NS - 1) % NS], rw[(u + NS - 1) % NS]);
+            const unsigned char *la = lds + cur * 2 * TILE, *lw = la + TILE;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 af[4], bfr[WJ];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8 *>(la + swz8(wr * 64 + i * 16 + fr, 4 * ks + fq));
+#pragma unroll
+                for (int j = 0; j < WJ; ++j)
+                    bfr[j] = *reinterpret_cast<const bf16x8 *>(lw + swz8(wc * WCOLS + j * 16 + fr, 4 * ks + fq));
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < WJ; ++j)
+                        // the operand that is contiguous in the OUTPUT goes first: a lane then holds 4 consecutive output
+                        // elements (C row-major: consecutive n -> W first; transposed store: consecutive m -> A first)
+                        acc[i][j] = TR ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8b, af[i]),
+                                                                                 __builtin_bit_cast(bf16x8b, bfr[j]), acc[i][j], 0, 0, 0)
+                                       : __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8b, bfr[j]),
+                                                                                 __builtin_bit_cast(bf16x8b, af[i]), acc[i][j], 0, 0, 0);
+            }
+            // tile kt + 1 (zeros beyond nk) -> the other buffer, last read before the previous barrier
+            lstore(cur ^ 1, ra[(u + 1) % NS], rw[(u + 1) % NS]);
+            // LDS-only barrier: __syncthreads() would also wait for the NS - 2 tiles of loads still in flight
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+    }
+    // epilogue: one vector store of 4 consecutive output elements per MFMA tile and lane
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < WJ; ++j) {
+            // TR: lane = (n = lane & 15, m = 4*(lane >> 4) + r); else lane = (m = lane & 15, n = 4*(lane >> 4) + r)
+            const int mb = m0 + wr * 64 + i * 16 + (TR ? (lane >> 4) * 4 : (lane & 15));
+            const int nb = n0 + wc * WCOLS + j * 16 + (TR ? (lane & 15) : (lane >> 4) * 4);
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = TR ? mb + r : mb, n = TR ? nb : nb + r;
+                float x = acc[i][j][r] * a.alpha;
+                if (bias) x += bias[min(n, N - 1)];
+                if (a.act == ACT_GELU) x = gelu_f(x);
+                if (R) x += R[(long)min(m, M - 1) * a.ldr + min(n, N - 1)];
+                v[r] = x;
+            }
+            TOUT *dst = TR ? C + (long)nb * a.ldc + mb : C + (long)mb * a.ldc + nb;
+            const bool full = TR ? (nb < N && mb + 3 < M) : (mb < M && nb + 3 < N);
+            if (full && (((uintptr_t)dst) % (4 * sizeof(TOUT))) == 0) {
+                if constexpr (sizeof(TOUT) == 4) {
+                    *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    __hip_bfloat16 h0 = __float2bfloat16(v[0]), h1 = __float2bfloat16(v[1]), h2 = __float2bfloat16(v[2]),
+                                   h3 = __float2bfloat16(v[3]);
+                    uint2 pk;
+                    pk.x = (unsigned)*reinterpret_cast<bf16_t *>(&h0) | ((unsigned)*reinterpret_cast<bf16_t *>(&h1) << 16);
+                    pk.y = (unsigned)*reinterpret_cast<bf16_t *>(&h2) | ((unsigned)*reinterpret_cast<bf16_t *>(&h3) << 16);
+                    *reinterpret_cast<uint2 *>(dst) = pk;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = TR ? mb + r : mb, n = TR ? nb : nb + r;
+                    if (m < M && n < N) store_out(TR ? C + (long)n * a.ldc + m : C + (long)m * a.ldc + n, v[r]);
+                }
+            }
+        }
+}
+
 }  // namespace
 
 void launch_gemm(const GemmArgs &a, DType in, DType out, hipStream_t st) {
@@ -228,8 +370,22 @@ void launch_gemm(const GemmArgs &a, DType in, DType out, hipStream_t st) {
     const bool bm64 = in == DType::BF16 && tiles128 < 200 && a.M > 64 && !no64;
     dim3 grid(ceil_div(a.N, BN), ceil_div(a.M, bm64 ? 64 : 128), a.nz0 * a.nz1);
     MW_CHECK(grid.y <= 65535, "gemm: M too large for grid.y");
+#define K64_LAUNCH(TOv, BMv)                                                                       \
+    do {                                                                                           \
+        if (a.trans_c) hipLaunchKernelGGL((gemm_bf16_k64_kernel<TOv, BMv, true>), grid, dim3(256), 0, st, a);  \
+        else hipLaunchKernelGGL((gemm_bf16_k64_kernel<TOv, BMv, false>), grid, dim3(256), 0, st, a);           \
+    } while (0)
+    static const bool k32 = getenv("MI355_WHISPER_GEMM_K32") != nullptr;  // experiments: the 32-deep k-step kernel
     if (in == DType::F32 && out == DType::F32)
         hipLaunchKernelGGL((gemm_nt_kernel<float, float, 128>), grid, dim3(256), 0, st, a);
+    else if (in == DType::BF16 && out == DType::F32 && bm64 && !k32)
+        K64_LAUNCH(float, 64);
+    else if (in == DType::BF16 && out == DType::F32 && !k32)
+        K64_LAUNCH(float, 128);
+    else if (in == DType::BF16 && out == DType::BF16 && bm64 && !k32)
+        K64_LAUNCH(bf16_t, 64);
+    else if (in == DType::BF16 && out == DType::BF16 && !k32)
+        K64_LAUNCH(bf16_t, 128);
     else if (in == DType::BF16 && out == DType::F32 && bm64)
         hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, float, 64>), grid, dim3(256), 0, st, a);
     else if (in == DType::BF16 && out == DType::F32)
@@ -240,6 +396,7 @@ void launch_gemm(const GemmArgs &a, DType in, DType out, hipStream_t st) {
         hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, bf16_t, 128>), grid, dim3(256), 0, st, a);
     else
         MW_CHECK(false, "gemm: unsupported dtype combination");
+#undef K64_LAUNCH
     MW_HIP(hipGetLastError());
 }
 
