@@ -49,8 +49,8 @@ def load_package():
 
 GEMV_CLASSES = {"qkv": 0, "attn_out": 1, "cross_q": 2, "fc1": 3, "fc2": 4, "logits": 5, "cross_attn": 7}
 KERNEL_NAMES = {"qkv": "proj_ln_tile_kernel<rows,EPI_QKV,16>", "cross_q": "proj_ln_tile_kernel<rows,EPI_SCALE,8>",
-                "fc1": "proj_ln_tile_kernel<rows,EPI_GELU_BF16,16>", "attn_out": "proj_res_tile_kernel<rows,5,1,8>",
-                "fc2": "proj_res_tile_kernel<rows,5,4,8>", "logits": "gemv_kernel<bf16,class=logits>",
+                "fc1": "proj_ln_tile_kernel<rows,EPI_GELU_BF16,32>", "attn_out": "proj_res_tile_kernel<rows,5,1,8>",
+                "fc2": "proj_res_tile_kernel<rows,5,4,8>", "logits": "logits_tile_kernel<rows,10>",
                 "cross_attn": "cross_attn_lean_kernel<rows>"}
 
 

@@ -19,7 +19,7 @@ CLASS_OF = {  # kernel-name fragments -> bench.py roofline class
     "cross_attn_lean_kernel": "cross_attn", "self_attn_lean_kernel": "self_attn",
     "proj_ln_tile_kernel<5, 0": "qkv", "proj_ln_tile_kernel<5, 2": "cross_q", "proj_ln_tile_kernel<5, 3": "fc1",
     "proj_res_tile_kernel<5, 5, 4": "fc2", "proj_res_tile_kernel<5, 5, 1": "attn_out",
-    "gemv_kernel<unsigned short, unsigned short, 5, 4, 5>": "logits", "logits_rules_kernel": "logits_rules",
+    "logits_tile_kernel<5": "logits", "enc_flash_attn_kernel": "enc_flash_attn", "logits_rules_kernel": "logits_rules",
     "logits_sumexp_kernel": "logits_sumexp", "logits_stats_kernel": "logits_stats", "logits_sample_kernel": "logits_sample",
 }
 
