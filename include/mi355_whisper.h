@@ -77,6 +77,11 @@ int mw_synchronize(struct whisper_context *ctx);
    (synthetic random weights otherwise end a window after a handful of tokens).  0 restores normal
    behaviour.  See DESIGN.md "forced decode length". */
 int mw_set_force_decode_steps(struct whisper_context *ctx, int n);
+/* Measurement-only: every launch of kernel class `step_class` (MW_STEP_*, -1: off) inside the replayed decode step is
+   issued twice (the second writes a scratch output where the kernel updates in place), so that
+   (time with - time without) / launches is the class's cost INSIDE graph replay; results are unchanged.  No
+   counterpart in the reference. */
+int mw_set_duplicate_class(struct whisper_context *ctx, int step_class);
 /* micro-benchmarks of single kernels on device-resident synthetic operands (bench.py roofline legs):
    run `iters` launches of the decode step's weight-streaming projections for `rows` activation rows and
    return the average milliseconds per launch measured with HIP events on the context's stream. */

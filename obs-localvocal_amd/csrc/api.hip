@@ -534,6 +534,12 @@ int mw_set_force_decode_steps(struct whisper_context *ctx, int n) {
     return 0;
 }
 
+int mw_set_duplicate_class(struct whisper_context *ctx, int step_class) {
+    if (!ctx || !ctx->c || step_class < -1 || step_class >= GEMV_N_TAGS + 2) return -1;
+    ctx->c->dup_tag = step_class;
+    return 0;
+}
+
 int mw_profile_begin(struct whisper_context *ctx, int gemv_class, int max_launches) {
     if (!ctx || !ctx->c || gemv_class < 0 || gemv_class >= GEMV_N_TAGS + 2 || max_launches <= 0 || max_launches > (1 << 20)) return -1;
     return guarded("mw_profile_begin", [&]() {

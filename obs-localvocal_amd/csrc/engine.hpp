@@ -89,6 +89,7 @@ struct Context {
     Timings tm;
     // live per-kernel timing of one projection class (bench.py roofline leg)
     int prof_tag = -1, prof_n = 0;
+    int dup_tag = -1;  // measurement: launches of this class are issued twice inside the replayed step (mw_set_duplicate_class)
     std::vector<hipEvent_t> prof_ev;
     // captured decode steps, keyed by (rows, logits rows, audio ctx, index-table parity)
     bool use_graphs = true;
