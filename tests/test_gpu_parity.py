@@ -127,6 +127,24 @@ def test_encoder_bf16_within_tolerance(pkg, engines, oracles, preset):
     assert rel < 0.01, rel
 
 
+@pytest.mark.parametrize("audio_ctx", [1500, 1000, 769, 64, 50])
+def test_encoder_bf16_audio_ctx_edges(pkg, engines, oracles, audio_ctx):
+    # reduced audio contexts (whisper_full_params.audio_ctx): the fused attention masks the keys beyond n_ctx in its last
+    # 64-key step (1000 -> 24 masked, 769 -> 63, 50 -> a single partial step), query tiles and GEMM tiles are ragged
+    eng, orc = engines("micro.en", pkg.PRECISION_BF16), oracles("micro.en")
+    pcm = ggml_io.synth_pcm(5, 30.0)
+    orc.mel(pcm)
+    eng.mel(pcm)
+    ref, got = orc.encode(0, audio_ctx), eng.encode(0, audio_ctx)
+    assert got.shape == ref.shape == (audio_ctx, orc.n_audio_state)
+    assert np.isfinite(got).all()
+    rel = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+    assert rel < 0.01, rel
+    # and back to the full context on the same engine: stale tiles of the shorter pass must not leak
+    ref, got = orc.encode(0), eng.encode(0)
+    assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 0.01
+
+
 # ---------------------------------------------------------------------------------------------
 # K7/K8 decoder
 # ---------------------------------------------------------------------------------------------
