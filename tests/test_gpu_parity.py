@@ -140,6 +140,11 @@ def test_encoder_bf16_audio_ctx_edges(pkg, engines, oracles, audio_ctx):
     assert np.isfinite(got).all()
     rel = np.linalg.norm(got - ref) / np.linalg.norm(ref)
     assert rel < 0.01, rel
+    # the decoder over that context: cross-attention split count / keys per split follow n_ctx (5 rows and 1 row)
+    toks = [orc.sot, 11, 22, 33, 44]
+    lr, lg = orc.decode(toks, 0, 0), eng.decode(toks, 0, 0)
+    assert np.abs(lg - lr).max() < 0.05
+    assert np.abs(eng.decode([55], 5, 0)[0] - orc.decode([55], 5, 0)[0]).max() < 0.05
     # and back to the full context on the same engine: stale tiles of the shorter pass must not leak
     ref, got = orc.encode(0), eng.encode(0)
     assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 0.01
