@@ -26,6 +26,14 @@ enum mw_precision {
    MI355_WHISPER_PRECISION is "fp32". */
 struct whisper_context *mw_init_from_file(const char *path_model, int gpu_device, int precision);
 struct whisper_context *mw_init_from_buffer(const void *buffer, size_t size, int gpu_device, int precision);
+/* A further context (one more audio stream / OBS source) on src's GPU that SHARES src's HBM-resident weights: nothing is
+   parsed or uploaded again; KV caches, workspace, HIP stream and whisper_full state are its own, so the two contexts run
+   concurrently from different threads.  The weights are freed with the last context that uses them (either may be freed
+   first).  whisper_init_from_file_with_params (whisper-processing.cpp:112) does this by itself when the same file
+   (path, size, mtime) is already resident on the same device in the same precision — one upload per GPU however many
+   filter instances load the model — unless MI355_WHISPER_NO_SHARED_WEIGHTS is set.  whisper.cpp's counterpart is
+   whisper_init_state, which LocalVocal does not call (one whisper_context per filter, whisper-utils.cpp:27-51). */
+struct whisper_context *mw_init_shared(struct whisper_context *src);
 
 /* model facts: n_vocab,n_audio_ctx,n_audio_state,n_audio_head,n_audio_layer,n_text_ctx,n_text_state,
    n_text_head,n_text_layer,n_mels,ftype */

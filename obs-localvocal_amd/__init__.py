@@ -101,7 +101,7 @@ EXPORTED_SYMBOLS = [
     "whisper_token_nosp", "whisper_token_not", "whisper_token_beg", "whisper_token_lang", "whisper_token_translate",
     "whisper_token_transcribe", "whisper_tokenize",
     "mw_full_device", "mw_profile_begin", "mw_profile_end",
-    "mw_init_from_file", "mw_init_from_buffer", "mw_hparams", "mw_pcm_to_mel", "mw_pcm_to_mel_device", "mw_mel_n_len",
+    "mw_init_from_file", "mw_init_from_buffer", "mw_init_shared", "mw_hparams", "mw_pcm_to_mel", "mw_pcm_to_mel_device", "mw_mel_n_len",
     "mw_get_mel", "mw_encode", "mw_get_encoder_out", "mw_get_cross_kv", "mw_decode", "mw_get_logits", "mw_kv_clear",
     "mw_process_logits", "mw_get_timings", "mw_reset_timings", "mw_stream", "mw_synchronize",
     "mw_set_force_decode_steps", "mw_set_duplicate_class", "mw_bench_decode_step", "mw_bench_mel", "mw_bench_encode", "mw_last_error",
@@ -182,6 +182,8 @@ def lib():
     L.mw_init_from_file.restype = P
     L.mw_init_from_file.argtypes = [C.c_char_p, C.c_int, C.c_int]
     L.mw_init_from_buffer.restype = P
+    L.mw_init_shared.restype = P
+    L.mw_init_shared.argtypes = [P]
     L.mw_init_from_buffer.argtypes = [P, C.c_size_t, C.c_int, C.c_int]
     L.mw_hparams.argtypes = [P, IP]
     L.mw_pcm_to_mel.argtypes = [P, FP, C.c_int]
@@ -273,10 +275,15 @@ def last_error() -> str:
 class Engine:
     """One whisper_context on one GPU."""
 
-    def __init__(self, model_path: str, precision: int = PRECISION_BF16, device: int = 0, ctx=None):
+    def __init__(self, model_path: str, precision: int = PRECISION_BF16, device: int = 0, ctx=None, share: "Engine | None" = None):
         self.L = lib()
         self._own = ctx is None
-        self.ctx = ctx if ctx is not None else self.L.mw_init_from_file(model_path.encode(), device, precision)
+        if ctx is not None:
+            self.ctx = ctx
+        elif share is not None:  # one more stream context on the weights `share` already uploaded
+            self.ctx = self.L.mw_init_shared(share.ctx)
+        else:
+            self.ctx = self.L.mw_init_from_file(model_path.encode(), device, precision)
         if not self.ctx:
             raise RuntimeError("mi355_whisper: failed to create context: " + last_error())
         hp = (C.c_int32 * 11)()

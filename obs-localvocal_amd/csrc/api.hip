@@ -5,6 +5,7 @@
 #include "../../include/mi355_whisper.h"
 
 #include <fstream>
+#include <sys/stat.h>
 #include <mutex>
 
 namespace mw {
@@ -66,8 +67,69 @@ whisper_context *init_from_buffer(const void *buffer, size_t size, int device, D
     return rc == 0 ? ctx : nullptr;
 }
 
+// Filter instances (OBS sources) that load the same model file on the same GPU share one HBM copy of the weights: the
+// registry keeps a view without ownership plus weak references; the arena is freed with its last context.
+struct SharedModelEntry {
+    std::string path;
+    int device;
+    DType wt;
+    long long size, mtime_ns;
+    Model view;  // owners reset
+    std::weak_ptr<void> arena, mel_tab;
+};
+std::mutex g_models_mutex;
+std::vector<SharedModelEntry> g_models;
+
+bool file_identity(const char *path, long long &size, long long &mtime_ns) {
+    struct stat sb;
+    if (stat(path, &sb) != 0) return false;
+    size = (long long)sb.st_size;
+    mtime_ns = (long long)sb.st_mtim.tv_sec * 1000000000ll + sb.st_mtim.tv_nsec;
+    return true;
+}
+
+whisper_context *init_shared_from(const Context &src) {
+    whisper_context *ctx = nullptr;
+    const int rc = guarded("whisper_init", [&]() {
+        std::unique_ptr<whisper_context> w(new whisper_context());
+        w->c = create_shared_context(src);
+        ctx = w.release();
+        return 0;
+    });
+    return rc == 0 ? ctx : nullptr;
+}
+
 whisper_context *init_from_file(const char *path, int device, DType wt) {
     if (!path) return nullptr;
+    long long fsize = 0, fmtime = 0;
+    const bool have_id = getenv("MI355_WHISPER_NO_SHARED_WEIGHTS") == nullptr && file_identity(path, fsize, fmtime);
+    if (have_id) {
+        // a context whose Model is a view of the registered weights (kept alive by the locked owners while it is built)
+        std::unique_ptr<Context> donor;
+        {
+            std::lock_guard<std::mutex> lk(g_models_mutex);
+            for (size_t i = 0; i < g_models.size();) {
+                SharedModelEntry &e = g_models[i];
+                std::shared_ptr<void> a = e.arena.lock(), t = e.mel_tab.lock();
+                if (!a || !t) {
+                    g_models.erase(g_models.begin() + i);
+                    continue;
+                }
+                if (!donor && e.path == path && e.device == device && e.wt == wt && e.size == fsize && e.mtime_ns == fmtime) {
+                    donor.reset(new Context());
+                    donor->device = device;
+                    donor->model = e.view;
+                    donor->model.arena_owner = a;
+                    donor->model.mel_tab_owner = t;
+                }
+                ++i;
+            }
+        }
+        if (donor) {
+            log_msg(LOG_INFO, "whisper_init_from_file: '%s' is already resident on device %d, sharing its weights\n", path, device);
+            return init_shared_from(*donor);
+        }
+    }
     std::vector<unsigned char> buf;
     const int rc = guarded("whisper_init", [&]() {
         std::ifstream f(path, std::ios::binary | std::ios::ate);
@@ -80,7 +142,15 @@ whisper_context *init_from_file(const char *path, int device, DType wt) {
     });
     if (rc != 0) return nullptr;
     log_msg(LOG_INFO, "whisper_init_from_file: loading model from '%s'\n", path);
-    return init_from_buffer(buf.data(), buf.size(), device, wt);
+    whisper_context *ctx = init_from_buffer(buf.data(), buf.size(), device, wt);
+    if (ctx && have_id) {
+        std::lock_guard<std::mutex> lk(g_models_mutex);
+        SharedModelEntry e{path, device, wt, fsize, fmtime, ctx->c->model, ctx->c->model.arena_owner, ctx->c->model.mel_tab_owner};
+        e.view.arena_owner.reset();
+        e.view.mel_tab_owner.reset();
+        g_models.push_back(std::move(e));
+    }
+    return ctx;
 }
 
 struct DeviceGuard {
@@ -150,6 +220,10 @@ struct whisper_context *mw_init_from_file(const char *path_model, int gpu_device
 }
 struct whisper_context *mw_init_from_buffer(const void *buffer, size_t size, int gpu_device, int precision) {
     return init_from_buffer(buffer, size, gpu_device, precision == MW_PRECISION_FP32 ? DType::F32 : DType::BF16);
+}
+struct whisper_context *mw_init_shared(struct whisper_context *src) {
+    if (!src || !src->c) return nullptr;
+    return init_shared_from(*src->c);
 }
 
 const char *whisper_print_system_info(void) {

@@ -61,7 +61,22 @@ Context::~Context() {
     if (st) (void)hipStreamDestroy(st);
 }
 
+namespace {
+std::unique_ptr<Context> create_context_impl(const unsigned char *data, size_t size, int device, DType wt, const Context *share);
+}
+
 std::unique_ptr<Context> create_context(const unsigned char *data, size_t size, int device, DType wt) {
+    return create_context_impl(data, size, device, wt, nullptr);
+}
+
+// A further stream context on the same GPU: its Model is a view of `src`'s HBM-resident weights (reference-counted,
+// nothing is uploaded again); workspace, KV caches, stream, graphs and whisper_full state are its own.
+std::unique_ptr<Context> create_shared_context(const Context &src) {
+    return create_context_impl(nullptr, 0, src.device, src.model.wt, &src);
+}
+
+namespace {
+std::unique_ptr<Context> create_context_impl(const unsigned char *data, size_t size, int device, DType wt, const Context *share) {
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
         throw std::runtime_error("no HIP device available: this engine has no CPU path");
@@ -74,7 +89,8 @@ std::unique_ptr<Context> create_context(const unsigned char *data, size_t size, 
     std::unique_ptr<Context> c(new Context());
     c->device = device;
     MW_HIP(hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking));
-    load_model(c->model, data, size, wt, c->st);
+    if (share) c->model = share->model;
+    else load_model(c->model, data, size, wt, c->st);
     const HParams &hp = c->model.hp;
     const size_t d = hp.n_audio_state, T = hp.n_audio_ctx, ws = dtype_size(wt), H = hp.n_audio_head;
     const size_t L = hp.n_text_layer, TC = hp.n_text_ctx, nv = hp.n_vocab;
@@ -183,11 +199,12 @@ std::unique_ptr<Context> create_context(const unsigned char *data, size_t size, 
         }
     }
     MW_HIP(hipStreamSynchronize(c->st));
-    log_msg(LOG_INFO, "mi355_whisper: model loaded (%zu params, %s weights, %.1f MB arena) on device %d (%s)\n",
-            c->model.n_params, wt == DType::F32 ? "fp32" : "bf16", c->model.arena_used / 1048576.0, device,
-            prop.gcnArchName);
+    log_msg(LOG_INFO, "mi355_whisper: %s (%zu params, %s weights, %.1f MB arena) on device %d (%s)\n",
+            share ? "stream context on shared weights" : "model loaded", c->model.n_params, wt == DType::F32 ? "fp32" : "bf16",
+            c->model.arena_used / 1048576.0, device, prop.gcnArchName);
     return c;
 }
+}  // namespace
 
 // ------------------------------------------------------------------------------------------
 // mel (A.2)

@@ -120,6 +120,8 @@ struct Context {
 
 // throws on failure
 std::unique_ptr<Context> create_context(const unsigned char *data, size_t size, int device, DType wt);
+// another stream context on src's GPU that shares src's uploaded weights (throws on failure)
+std::unique_ptr<Context> create_shared_context(const Context &src);
 
 // stage entry points (used by whisper_full and by the parity API)
 void pcm_to_mel(Context &c, const float *pcm, int n_samples, bool pcm_on_device);

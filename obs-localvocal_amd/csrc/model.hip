@@ -276,10 +276,11 @@ std::vector<int> Vocab::tokenize(const std::string &text) const {
     return tokens;
 }
 
-Model::~Model() {
-    if (arena) (void)hipFree(arena);
-    if (d_mel_tab) (void)hipFree(d_mel_tab);
+namespace {
+void free_device_block(void *p) {
+    if (p) (void)hipFree(p);
 }
+}  // namespace
 
 void load_model(Model &m, const unsigned char *data, size_t size, DType wt, hipStream_t st) {
     Cursor c{data, data + size};
@@ -370,6 +371,7 @@ void load_model(Model &m, const unsigned char *data, size_t size, DType wt, hipS
                        Ld * (3 * d + d + d + d + 4 * d + d + 6 * d + 2 * d) + 4 * d + 64;
     m.arena_size = mat_elems * ws + vec_elems * 4 + (64 + 16 * (Le + Ld)) * 256 + (1 << 20);
     MW_HIP(hipMalloc((void **)&m.arena, m.arena_size));
+    m.arena_owner = std::shared_ptr<void>(m.arena, free_device_block);
     L.staging_size = max_bytes;
     MW_HIP(hipMalloc(&L.staging, max_bytes));
     try {
@@ -442,6 +444,7 @@ void load_model(Model &m, const unsigned char *data, size_t size, DType wt, hipS
         MelTables tab;
         build_mel_tables(m, tab);
         MW_HIP(hipMalloc((void **)&m.d_mel_tab, sizeof(MelTables)));
+        m.mel_tab_owner = std::shared_ptr<void>(m.d_mel_tab, free_device_block);
         MW_HIP(hipMemcpyAsync(m.d_mel_tab, &tab, sizeof(tab), hipMemcpyHostToDevice, st));
         MW_HIP(hipStreamSynchronize(st));
     } catch (...) {

@@ -11,6 +11,7 @@
 #include "kernels.hpp"
 
 #include <map>
+#include <memory>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -91,11 +92,9 @@ struct Model {
     char *arena = nullptr;
     size_t arena_size = 0, arena_used = 0;
     size_t n_params = 0;
-
-    ~Model();
-    Model() = default;
-    Model(const Model &) = delete;
-    Model &operator=(const Model &) = delete;
+    // the device allocations (arena, mel tables) are reference-counted: a copy of a Model is a view of the same
+    // HBM-resident weights (one upload per GPU, any number of stream contexts: mw_init_shared)
+    std::shared_ptr<void> arena_owner, mel_tab_owner;
 };
 
 // Parses `size` bytes at `data` (a whole ggml-*.bin image) and uploads to the current HIP device.

@@ -102,6 +102,49 @@ def test_contexts_are_reentrant_across_threads(pkg, model_file):
     assert out == alone
 
 
+def test_stream_contexts_share_one_weight_upload(pkg, model_file, monkeypatch):
+    # configs[3]: many streams per GPU, weights resident once.  mw_init_shared (and whisper_init_from_file on a file that
+    # is already resident) gives a context of its own on the same weights; the weights outlive the context that uploaded
+    # them for as long as another context uses them.
+    import threading
+    path = model_file("micro", ftype=1)
+    clips = [ggml_io.synth_pcm(300 + i, 6.0) for i in range(3)]
+    monkeypatch.setenv("MI355_WHISPER_NO_SHARED_WEIGHTS", "1")     # reference run: every context uploads its own copy
+    alone = [_forced_tokens(pkg, path, c, 16, pkg.PRECISION_BF16, language="en")[0] for c in clips]
+    monkeypatch.delenv("MI355_WHISPER_NO_SHARED_WEIGHTS")
+    first = pkg.Engine(path, precision=pkg.PRECISION_BF16)
+    second = pkg.Engine(path, precision=pkg.PRECISION_BF16, share=first)   # explicit
+    third = pkg.Engine(path, precision=pkg.PRECISION_BF16)                 # same file, same device: shared by the loader
+    engs = [first, second, third]
+    out, errs = [None] * 3, []
+
+    def work(i, e):
+        try:
+            e.set_force_decode_steps(16)
+            p = e.default_params(0, temperature_inc=0.0, duration_ms=6000, language="en")
+            assert e.full(p, clips[i]) == 0
+            out[i] = e.token_ids()
+        except Exception as ex:  # noqa: BLE001
+            errs.append(repr(ex))
+
+    try:
+        th = [threading.Thread(target=work, args=(i, engs[i])) for i in range(3)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, errs
+        assert out == alone
+        first.close()            # the uploader goes first; the views keep the weights alive
+        work(1, second)
+        work(2, third)
+        assert not errs, errs
+        assert out == alone
+    finally:
+        for e in engs:
+            e.close()
+
+
 @pytest.mark.parametrize("width,heads", [(384, 6), (512, 8), (768, 12), (1024, 16), (1280, 20)])
 def test_tile_kernels_every_model_width_bf16(pkg, model_file, width, heads):
     # The beam-step tile kernels are specialised per width (k-steps per wave, chunks per row, vocabulary chunks of the
