@@ -16,6 +16,8 @@
 
 #include <hip/hip_bf16.h>
 
+#include <cmath>
+
 namespace mw {
 
 namespace {
@@ -24,6 +26,7 @@ using bf16x8 = __attribute__((ext_vector_type(8))) short;   // 8 bf16 = 4 VGPRs 
 using bf16x8b = __attribute__((ext_vector_type(8))) __bf16;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
 constexpr int BN = 128;  // BM (128 or 64 rows) is a template parameter: 64 doubles the tiles of narrow-N shapes
 constexpr int ROW_BYTES = 64;  // K-extent of one LDS tile row: 32 bf16 or 16 f32
@@ -46,6 +49,31 @@ __device__ __forceinline__ int swz(int r, int c) {
     return r * ROW_BYTES + ((c ^ g) << 4);
 }
 
+// ---- XCD-aware tile order ----
+// Workgroups are dealt round-robin over the 8 XCDs in dispatch order (ids b and b + 8 share an XCD and its 4 MiB L2), so with
+// tile = blockIdx every XCD touches every row panel of A and of W: each L2 pulls both operands whole from the Infinity Cache,
+// and a CU reads from there at half the rate it reads from its L2 (the M = 1500 encoder GEMMs ran at the per-CU Infinity
+// Cache rate, ~27 GB/s per CU, not at an MFMA or LDS limit).  The remap gives the workgroups that share an XCD one contiguous
+// range of a tile order made of super-rows of hb M-tiles, N-tile outer, M-tile inner: with hb chosen by launch_gemm a range
+// is a compact hb x w rectangle of tiles (or whole batch slices), whose operand panels are fetched into that L2 once.
+// Bijective for any grid and any hb >= 1; which XCD a label lands on does not matter (performance only, never correctness).
+struct TileCoord {
+    int tm, tn, z;
+};
+__device__ __forceinline__ TileCoord xcd_tile_coord(int hb) {
+    const unsigned gx = gridDim.x, gy = gridDim.y;
+    if (hb <= 0) return {(int)blockIdx.y, (int)blockIdx.x, (int)blockIdx.z};
+    const unsigned T = gx * gy, G = T * gridDim.z;
+    const unsigned id = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned xcd = id & 7, q = G >> 3, r = G & 7;
+    const unsigned nl = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+    const unsigned z = nl / T, lin = nl - z * T;
+    const unsigned per = (unsigned)hb * gx, s = lin / per, rem = lin - s * per;
+    const unsigned rows = min((unsigned)hb, gy - s * (unsigned)hb);
+    const unsigned tn = rem / rows;
+    return {(int)(s * (unsigned)hb + (rem - tn * rows)), (int)tn, (int)z};
+}
+
 template <typename TIN, typename TOUT, int BM>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
     constexpr bool F32 = sizeof(TIN) == 4;
@@ -59,13 +87,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = BM == 128 ? wave >> 1 : 0, wc = BM == 128 ? wave & 1 : wave;
     constexpr int WCOLS = BM == 128 ? 64 : 32;  // columns per wave
-    const int z0 = blockIdx.z / a.nz1, z1 = blockIdx.z % a.nz1;
+    const TileCoord tc = xcd_tile_coord(a.hb);
+    const int z0 = tc.z / a.nz1, z1 = tc.z % a.nz1;
     const TIN *A = (const TIN *)a.A + z0 * a.sA0 + z1 * a.sA1;
     const TIN *W = (const TIN *)a.W + z0 * a.sW0 + z1 * a.sW1;
     TOUT *C = (TOUT *)a.C + z0 * a.sC0 + z1 * a.sC1;
     const float *bias = a.bias ? a.bias + z0 * a.sB0 + z1 * a.sB1 : nullptr;
     const float *R = a.R ? a.R + z0 * a.sR0 + z1 * a.sR1 : nullptr;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int m0 = tc.tm * BM, n0 = tc.tn * BN;
     const int M = a.M, N = a.N, K = a.K;
 
     // this thread's two 16-byte chunks per operand tile: idx = tid + 256 q -> row idx>>2, chunk idx&3
@@ -214,20 +243,27 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
 // iteration: the loop is bound by the latency of the next tile's global loads (one barrier and one wait per
 // iteration), so halving the iterations nearly halves the time.  LDS rows are 128 bytes, 16-byte chunk c of row r
 // lives at chunk c ^ (r & 7); every load is unconditional (clamped address, zero selected afterwards).
-template <typename TOUT, int BM, bool TR>
+//
+// PIN: the ring's loads are pinned to the top of the k-step (scheduling barrier behind them).  Pinned, three steps of
+// loads are really in flight, at the price of ~280 registers (one workgroup per CU): the choice for grids of at most one
+// tile per CU (the encoder's M = 1500 shapes).  Unpinned, hipcc moves the loads behind the step's products and keeps two
+// workgroups per CU: better when a CU has several tiles to overlap (cross-K/V over 32 layers, fc1).
+template <typename TOUT, int BM, bool TR, bool PIN>
 __global__ __launch_bounds__(256) void gemm_bf16_k64_kernel(GemmArgs a) {
+    constexpr int SK = 1, grp = 0;  // (an in-workgroup k-split over two 4-wave groups was measured: no gain)
     constexpr int BK = 64, RB = 128, TILE = 128 * RB;
     constexpr int WJ = BM == 128 ? 4 : 2, WCOLS = BM == 128 ? 64 : 32, QA = BM == 128 ? 4 : 2;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = BM == 128 ? wave >> 1 : 0, wc = BM == 128 ? wave & 1 : wave;
-    const int z0 = blockIdx.z / a.nz1, z1 = blockIdx.z % a.nz1;
+    const TileCoord tc = xcd_tile_coord(a.hb);
+    const int z0 = tc.z / a.nz1, z1 = tc.z % a.nz1;
     const bf16_t *A = (const bf16_t *)a.A + z0 * a.sA0 + z1 * a.sA1;
     const bf16_t *W = (const bf16_t *)a.W + z0 * a.sW0 + z1 * a.sW1;
     TOUT *C = (TOUT *)a.C + z0 * a.sC0 + z1 * a.sC1;
     const float *bias = a.bias ? a.bias + z0 * a.sB0 + z1 * a.sB1 : nullptr;
     const float *R = a.R ? a.R + z0 * a.sR0 + z1 * a.sR1 : nullptr;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int m0 = tc.tm * BM, n0 = tc.tn * BN;
     const int M = a.M, N = a.N, K = a.K;
     auto swz8 = [](int r, int c) { return r * RB + ((c ^ (r & 7)) << 4); };
     // this thread's 16-byte chunks: idx = tid + 256 q -> row idx >> 3, chunk idx & 7
@@ -241,32 +277,40 @@ __global__ __launch_bounds__(256) void gemm_bf16_k64_kernel(GemmArgs a) {
         gw[q] = W + (long)min(n0 + row, N - 1) * a.ldw + chk * 8;
     }
     const int kchk = (tid & 7) * 8;  // k offset of this thread's chunks inside a k-step
-    const int nk = (K + BK - 1) / BK;
+    const int nk_all = (K + BK - 1) / BK;
+    const int nk = (nk_all + SK - 1) / SK;  // k-steps of this group: its step kt is step kt * SK + grp of the product
     // Register ring of NS k-steps: the loads of step kt + NS - 1 are issued while step kt is multiplied, so a load has
     // NS - 2 iterations (not one) to arrive before its tile goes to LDS.  The k-loop is unrolled by NS so that every
     // ring index is a constant; steps beyond nk reload the last tile (clamped) and store zeros: no branch in the loop.
     constexpr int NS = 4;
-    uint4 ra[NS][QA], rw[NS][4];
-    auto gload = [&](int kt, uint4(&pa)[QA], uint4(&pw)[4]) {
-        const int kc = min(kt, nk - 1);
-        const bool ok = kt < nk && kc * BK + kchk < K;
+    // Every load is unconditional (clamped address); a chunk beyond K or a step beyond nk is zeroed by an AND with the ring
+    // slot's mask when the tile goes to LDS.  A select on the loaded value made hipcc sink the loads under an exec-masked
+    // branch, and behind the joins of those branches it waited for vmcnt(0) in every k-step: the ring never had more than
+    // one step in flight and a k-step took a full load latency (~1 us for 0.2 us of matrix work).  The mask passes
+    // through an empty asm so that it stays an opaque register and the AND is not folded back into a select.
+    // (The loads stay compiler-visible on purpose: as inline asm with hand-counted vmcnt, hipcc parked ring registers in
+    // AGPRs across the back-edge, copying registers whose loads were still in flight: wrong tiles under memory load.)
+    u32x4 ra[NS][QA], rw[NS][4];
+    unsigned rm[NS];
+    auto gload = [&](int kt, u32x4(&pa)[QA], u32x4(&pw)[4], unsigned &pm) {
+        const int ks_all = kt * SK + grp, kc = min(ks_all, nk_all - 1);
+        const bool ok = kt < nk && ks_all < nk_all && kc * BK + kchk < K;
         const long off = kc * BK + kchk < K ? (long)kc * BK : 0;
+        unsigned m = ok ? 0xffffffffu : 0u;
+        asm volatile("" : "+v"(m));
+        pm = m;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            if (q < QA) {
-                const uint4 t = *reinterpret_cast<const uint4 *>(ga[q] + off);
-                pa[q] = ok ? t : make_uint4(0, 0, 0, 0);
-            }
-            const uint4 u = *reinterpret_cast<const uint4 *>(gw[q] + off);
-            pw[q] = ok ? u : make_uint4(0, 0, 0, 0);
+            if (q < QA) pa[q] = *reinterpret_cast<const u32x4 *>(ga[q] + off);
+            pw[q] = *reinterpret_cast<const u32x4 *>(gw[q] + off);
         }
     };
-    auto lstore = [&](int buf, const uint4(&pa)[QA], const uint4(&pw)[4]) {
+    auto lstore = [&](int buf, const u32x4(&pa)[QA], const u32x4(&pw)[4], unsigned m) {
         unsigned char *la = lds + buf * 2 * TILE, *lw = la + TILE;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            if (q < QA) *reinterpret_cast<uint4 *>(la + lo[q]) = pa[q];
-            *reinterpret_cast<uint4 *>(lw + lo[q]) = pw[q];
+            if (q < QA) *reinterpret_cast<u32x4 *>(la + lo[q]) = pa[q] & m;
+            *reinterpret_cast<u32x4 *>(lw + lo[q]) = pw[q] & m;
         }
     };
     f32x4 acc[4][WJ];
@@ -275,15 +319,18 @@ __global__ __launch_bounds__(256) void gemm_bf16_k64_kernel(GemmArgs a) {
 #pragma unroll
         for (int j = 0; j < WJ; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
 #pragma unroll
-    for (int u = 0; u < NS - 1; ++u) gload(u, ra[u], rw[u]);
-    lstore(0, ra[0], rw[0]);
+    for (int u = 0; u < NS - 1; ++u) gload(u, ra[u], rw[u], rm[u]);
+    lstore(0, ra[0], rw[0], rm[0]);
     __syncthreads();
     const int fr = lane & 15, fq = lane >> 4;
     for (int kt0 = 0; kt0 < nk; kt0 += NS) {
 #pragma unroll
         for (int u = 0; u < NS; ++u) {
             const int kt = kt0 + u, cur = u & 1;  // NS is even: the LDS buffer parity of step kt is that of u
-            gload(kt + NS - 1, ra[(u + NS - 1) % NS], rw[(u + NS - 1) % NS]);
+            gload(kt + NS - 1, ra[(u + NS - 1) % NS], rw[(u + NS - 1) % NS], rm[(u + NS - 1) % NS]);
+            // the loads are issued HERE, NS - 1 steps ahead of their use: left alone, the scheduler moved them behind the
+            // products of the step (shorter live ranges) and the ring was one step deep again
+            if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
             const unsigned char *la = lds + cur * 2 * TILE, *lw = la + TILE;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -305,7 +352,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_k64_kernel(GemmArgs a) {
                                                                                  __builtin_bit_cast(bf16x8b, af[i]), acc[i][j], 0, 0, 0);
             }
             // tile kt + 1 (zeros beyond nk) -> the other buffer, last read before the previous barrier
-            lstore(cur ^ 1, ra[(u + 1) % NS], rw[(u + 1) % NS]);
+            lstore(cur ^ 1, ra[(u + 1) % NS], rw[(u + 1) % NS], rm[(u + 1) % NS]);
             // LDS-only barrier: __syncthreads() would also wait for the NS - 2 tiles of loads still in flight
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
@@ -353,7 +400,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_k64_kernel(GemmArgs a) {
 
 }  // namespace
 
-void launch_gemm(const GemmArgs &a, DType in, DType out, hipStream_t st) {
+void launch_gemm(const GemmArgs &args, DType in, DType out, hipStream_t st) {
+    GemmArgs a = args;
     MW_CHECK(a.A && a.W && a.C, "gemm: null operand");
     MW_CHECK(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty shape");
     const int epc = in == DType::F32 ? 4 : 8;  // elements per 16-byte chunk
@@ -370,10 +418,34 @@ void launch_gemm(const GemmArgs &a, DType in, DType out, hipStream_t st) {
     const bool bm64 = in == DType::BF16 && tiles128 < 200 && a.M > 64 && !no64;
     dim3 grid(ceil_div(a.N, BN), ceil_div(a.M, bm64 ? 64 : 128), a.nz0 * a.nz1);
     MW_CHECK(grid.y <= 65535, "gemm: M too large for grid.y");
-#define K64_LAUNCH(TOv, BMv)                                                                       \
-    do {                                                                                           \
-        if (a.trans_c) hipLaunchKernelGGL((gemm_bf16_k64_kernel<TOv, BMv, true>), grid, dim3(256), 0, st, a);  \
-        else hipLaunchKernelGGL((gemm_bf16_k64_kernel<TOv, BMv, false>), grid, dim3(256), 0, st, a);           \
+    {   // XCD-aware tile order (xcd_tile_coord): super-row height for which an XCD's share of the tiles is a compact rectangle
+        static const bool no_remap = getenv("MI355_WHISPER_GEMM_NO_XCD") != nullptr;  // experiments: tile = blockIdx
+        const long T = (long)grid.x * grid.y, G = T * grid.z, share = (G + 7) / 8;
+        a.hb = 0;
+        if (!no_remap && G >= 16 && G < (1L << 31)) {
+            if (share >= T) {
+                a.hb = (int)grid.y;  // an XCD gets whole batch slices: any order inside a slice
+            } else {
+                // rectangle of `share` tiles with equal operand bytes on both sides: h * BM = w * BN  ->  h = sqrt(share * BN / BM)
+                const double h = sqrt((double)share * BN / (bm64 ? 64 : 128));
+                double best = 1e30;
+                for (int xm = 1; xm <= 8; xm *= 2) {
+                    const int hb = ceil_div((int)grid.y, xm);
+                    if (fabs(hb - h) < best) best = fabs(hb - h), a.hb = hb;
+                }
+            }
+        }
+    }
+    // pinned load ring (one workgroup per CU) when the grid has at most one tile per CU anyway
+    static const char *pin_env = getenv("MI355_WHISPER_GEMM_PIN");  // experiments: 0 / 1 force the variant
+    // (64-row tiles keep two workgroups per CU pinned or not: always pinned)
+    const bool pin = pin_env ? pin_env[0] == '1' : (bm64 || (long)grid.x * grid.y * grid.z <= 256);
+#define K64_LAUNCH(TOv, BMv)                                                                                                \
+    do {                                                                                                                    \
+        if (pin && a.trans_c) hipLaunchKernelGGL((gemm_bf16_k64_kernel<TOv, BMv, true, true>), grid, dim3(256), 0, st, a);  \
+        else if (pin) hipLaunchKernelGGL((gemm_bf16_k64_kernel<TOv, BMv, false, true>), grid, dim3(256), 0, st, a);         \
+        else if (a.trans_c) hipLaunchKernelGGL((gemm_bf16_k64_kernel<TOv, BMv, true, false>), grid, dim3(256), 0, st, a);   \
+        else hipLaunchKernelGGL((gemm_bf16_k64_kernel<TOv, BMv, false, false>), grid, dim3(256), 0, st, a);                 \
     } while (0)
     static const bool k32 = getenv("MI355_WHISPER_GEMM_K32") != nullptr;  // experiments: the 32-deep k-step kernel
     if (in == DType::F32 && out == DType::F32)

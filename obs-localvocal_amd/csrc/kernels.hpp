@@ -61,6 +61,7 @@ struct GemmArgs {
     float alpha = 1.0f;
     int act = ACT_NONE;
     int trans_c = 0;
+    int hb = 0;  // set by launch_gemm: M-tiles per super-row of the XCD-aware tile order (0: tile = blockIdx)
 };
 // in: element type of A and W; out: element type of C
 void launch_gemm(const GemmArgs &a, DType in, DType out, hipStream_t st);
