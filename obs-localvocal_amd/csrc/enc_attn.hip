@@ -24,6 +24,7 @@ namespace {
 
 using bf16x8b = __attribute__((ext_vector_type(8))) __bf16;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
 constexpr int FQ = 128;      // queries per workgroup
 constexpr int FK = 64;       // keys per step
@@ -53,21 +54,28 @@ __global__ __launch_bounds__(256) void enc_flash_attn_kernel(const bf16_t *__res
             qf[i][s] = *reinterpret_cast<const uint4 *>(qk + (long)min(q0 + 16 * i + fr, n_ctx - 1) * ldq + h * 64 + 32 * s + 8 * fq);
     // tile loader: thread -> row tid>>2 (a key of K / a dim of V^T), 32 bytes at element (tid&3)*16
     const int lrow = tid >> 2, lcol = (tid & 3) * 16;
-    uint4 rk[2], rv[2];
-    auto gload = [&](int step) {
-        const bf16_t *kp = qk + (long)min(step * FK + lrow, n_ctx - 1) * ldq + d + h * 64 + lcol;
-        const bf16_t *vp = vt + (long)(h * 64 + lrow) * tp + step * FK + lcol;
-        rk[0] = *reinterpret_cast<const uint4 *>(kp);
-        rk[1] = *reinterpret_cast<const uint4 *>(kp + 8);
-        rv[0] = *reinterpret_cast<const uint4 *>(vp);
-        rv[1] = *reinterpret_cast<const uint4 *>(vp + 8);
-    };
-    auto lstore = [&](int buf) {
-        *reinterpret_cast<uint4 *>(&kt[buf][lrow * FLD + lcol]) = rk[0];
-        *reinterpret_cast<uint4 *>(&kt[buf][lrow * FLD + lcol + 8]) = rk[1];
-        *reinterpret_cast<uint4 *>(&vs[buf][lrow * FLD + lcol]) = rv[0];
-        *reinterpret_cast<uint4 *>(&vs[buf][lrow * FLD + lcol + 8]) = rv[1];
-    };
+    // The next step's K / V^T pieces travel in four first-class vector registers, loaded unconditionally (the step index
+    // is clamped: the last step reloads its own tile).  As `uint4 rk[2], rv[2]` filled by a lambda under `if (step + 1 <
+    // nsteps)` hipcc kept the arrays in scratch memory: every step waited for its loads at once to copy them there
+    // (vmcnt right behind the loads), i.e. one full memory latency per step, 62 us per layer.
+    u32x4 rk0, rk1, rv0, rv1;
+#define ENC_GLOAD(step_)                                                                                  \
+    do {                                                                                                  \
+        const int s_ = (step_);                                                                           \
+        const bf16_t *kp = qk + (long)min(s_ * FK + lrow, n_ctx - 1) * ldq + d + h * 64 + lcol;           \
+        const bf16_t *vp = vt + (long)(h * 64 + lrow) * tp + s_ * FK + lcol;                              \
+        rk0 = *reinterpret_cast<const u32x4 *>(kp);                                                       \
+        rk1 = *reinterpret_cast<const u32x4 *>(kp + 8);                                                   \
+        rv0 = *reinterpret_cast<const u32x4 *>(vp);                                                       \
+        rv1 = *reinterpret_cast<const u32x4 *>(vp + 8);                                                   \
+    } while (0)
+#define ENC_LSTORE(buf_)                                                                  \
+    do {                                                                                  \
+        *reinterpret_cast<u32x4 *>(&kt[buf_][lrow * FLD + lcol]) = rk0;                   \
+        *reinterpret_cast<u32x4 *>(&kt[buf_][lrow * FLD + lcol + 8]) = rk1;               \
+        *reinterpret_cast<u32x4 *>(&vs[buf_][lrow * FLD + lcol]) = rv0;                   \
+        *reinterpret_cast<u32x4 *>(&vs[buf_][lrow * FLD + lcol + 8]) = rv1;               \
+    } while (0)
     f32x4 o[2][4];
     float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.0f, 0.0f};
 #pragma unroll
@@ -75,12 +83,12 @@ __global__ __launch_bounds__(256) void enc_flash_attn_kernel(const bf16_t *__res
 #pragma unroll
         for (int t = 0; t < 4; ++t) o[i][t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     const int nsteps = tp / FK;
-    gload(0);
-    lstore(0);
+    ENC_GLOAD(0);
+    ENC_LSTORE(0);
     __syncthreads();
     for (int step = 0; step < nsteps; ++step) {
         const int cur = step & 1;
-        if (step + 1 < nsteps) gload(step + 1);
+        ENC_GLOAD(min(step + 1, nsteps - 1));
         const bf16_t *kb = kt[cur], *vb = vs[cur];
         // ---- S^T tiles ----
         f32x4 sa[2][4];
@@ -150,10 +158,9 @@ __global__ __launch_bounds__(256) void enc_flash_attn_kernel(const bf16_t *__res
                     o[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8b, af), __builtin_bit_cast(bf16x8b, pb[i][c]),
                                                                       o[i][t], 0, 0, 0);
             }
-        if (step + 1 < nsteps) {
-            lstore(cur ^ 1);  // the other buffer was last read before the previous barrier
-            __syncthreads();
-        }
+        // the other buffer was last read before the previous barrier (after the last step: a harmless rewrite)
+        ENC_LSTORE(cur ^ 1);
+        __syncthreads();
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -173,6 +180,9 @@ __global__ __launch_bounds__(256) void enc_flash_attn_kernel(const bf16_t *__res
         }
     }
 }
+
+#undef ENC_GLOAD
+#undef ENC_LSTORE
 
 }  // namespace
 
