@@ -302,7 +302,7 @@ __global__ __launch_bounds__(PT) void logits_sample_kernel(const float *__restri
                                                            float *__restrict__ dump_probs) {
     __shared__ double wtot[PW];
     const int tid = threadIdx.x, r = blockIdx.y, g = blockIdx.x, nv = P.n_vocab, beg = P.beg;
-    const LogitsRowState S = rows[r];
+    const LogitsRowState &S = rows[r];  // by reference: a by-value copy lives in scratch (u[] is indexed in loops)
     const RowView V = row_view(logits, ld, work, S, nv);
     __shared__ SlabRec srec[PG];
     const SlabRec *rec = stage_records(V.rec, srec);
