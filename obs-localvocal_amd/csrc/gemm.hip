@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_k64_kernel(GemmArgs a) {
     // Register ring of NS k-steps: the loads of step kt + NS - 1 are issued while step kt is multiplied, so a load has
     // NS - 2 iterations (not one) to arrive before its tile goes to LDS.  The k-loop is unrolled by NS so that every
     // ring index is a constant; steps beyond nk reload the last tile (clamped) and store zeros: no branch in the loop.
-    constexpr int NS = 4;
+    constexpr int NS = PIN ? 4 : 2;  // unpinned variant: one step ahead, pinned too (see PIN)
     // Every load is unconditional (clamped address); a chunk beyond K or a step beyond nk is zeroed by an AND with the ring
     // slot's mask when the tile goes to LDS.  A select on the loaded value made hipcc sink the loads under an exec-masked
     // branch, and behind the joins of those branches it waited for vmcnt(0) in every k-step: the ring never had more than
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_k64_kernel(GemmArgs a) {
             gload(kt + NS - 1, ra[(u + NS - 1) % NS], rw[(u + NS - 1) % NS], rm[(u + NS - 1) % NS]);
             // the loads are issued HERE, NS - 1 steps ahead of their use: left alone, the scheduler moved them behind the
             // products of the step (shorter live ranges) and the ring was one step deep again
-            if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);
             const unsigned char *la = lds + cur * 2 * TILE, *lw = la + TILE;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
