@@ -140,6 +140,7 @@ std::unique_ptr<Context> create_context_impl(const unsigned char *data, size_t s
     c->decoders[0].rng = std::mt19937(0);
     c->n_ctx_cur = (int)T;
     if (getenv("MI355_WHISPER_NO_GRAPH")) c->use_graphs = false;  // debugging aid: eager launches
+    if (getenv("MI355_WHISPER_NO_FUSED_SAMPLE")) c->fuse_sample = false;  // rules + samplers as launches of their own
     // the matrix-core projection variant measured ~5 % slower per window than the VALU one at 5 rows
     // (profiles/r01_*): kept selectable for wider batches
     c->flash_attn = wt == DType::BF16 && getenv("MI355_WHISPER_NO_FLASH_ATTN") == nullptr;
@@ -430,7 +431,16 @@ void decode(Context &c, const int *tokens, const int *pos, const int *slot, int 
     hu[KV_SLOTS] = c.reorder_n_past;
     hu[KV_SLOTS + 1] = c.reorder_pending ? 1 : 0;
     c.reorder_pending = false;
-    const size_t step_bytes = (size_t)(3 * TC + LOGIT_ROWS + KV_SLOTS + 2) * sizeof(int);
+    size_t step_bytes = (size_t)(3 * TC + LOGIT_ROWS + KV_SLOTS + 2) * sizeof(int);
+    // prepared rules + sampler rows (prepare_sample): appended to the step block, 8-byte aligned
+    const size_t rs_off = (step_bytes + 7) / 8 * 8;
+    const bool fuse = c.ps_armed && c.fuse_sample && c.use_graphs && c.prof_tag < 0 && !c.use_mega && n_logit_rows > 0 &&
+                      rs_off + (size_t)c.ps_n * sizeof(LogitsRowState) <= (size_t)4 * TC * sizeof(int);
+    if (fuse) {
+        memcpy((char *)hi + rs_off, c.h_row_state, (size_t)c.ps_n * sizeof(LogitsRowState));
+        step_bytes = rs_off + (size_t)c.ps_n * sizeof(LogitsRowState);
+    }
+    const LogitsRowState *d_rs_block = reinterpret_cast<const LogitsRowState *>((const char *)c.d_tokens + rs_off);
     // Everything below is one fixed launch sequence for a given (rows, logits rows, index table, audio
     // context): it is captured into a hipGraph once and replayed, because the step is launch-bound
     // (~290 launches of 3-10 us kernels).  Per-step values (tokens, positions, slots) travel through
@@ -544,6 +554,11 @@ void decode(Context &c, const int *tokens, const int *pos, const int *slot, int 
             g.tag = GEMV_LOGITS;
             gemv2(g);
         }
+        if (fuse) {
+            launch_process_logits(c.d_logits, hp.n_vocab, c.d_suppress, c.ps_lp, d_rs_block, c.d_row_res, c.ps_n, c.d_work, nullptr,
+                                  nullptr, nullptr, st);
+            MW_HIP(hipMemcpyAsync(c.h_row_res, c.d_row_res, c.ps_n * sizeof(LogitsRowResult), hipMemcpyDeviceToHost, st));
+        }
     };
     const bool use_graph = c.use_graphs && c.prof_tag < 0;
     if (c.use_mega && n <= 5 && c.prof_tag < 0) {
@@ -578,8 +593,17 @@ void decode(Context &c, const int *tokens, const int *pos, const int *slot, int 
     } else if (!use_graph) {
         enqueue();
     } else {
-        const uint64_t key = ((uint64_t)(c.dup_tag + 1) << 56) | ((uint64_t)n << 40) | ((uint64_t)n_logit_rows << 24) | ((uint64_t)n_ctx << 4) |
-                             (uint64_t)c.kv_cur;
+        uint64_t key = ((uint64_t)(c.dup_tag + 1) << 56) | ((uint64_t)n << 40) | ((uint64_t)n_logit_rows << 24) | ((uint64_t)n_ctx << 4) |
+                       (uint64_t)c.kv_cur;
+        if (fuse) {  // the rules' parameters are kernel arguments of the captured nodes: part of the key (FNV-1a over their bytes)
+            uint64_t h = 1469598103934665603ull;
+            auto mix = [&](const void *p, size_t nb) {
+                for (size_t i = 0; i < nb; ++i) h = (h ^ ((const unsigned char *)p)[i]) * 1099511628211ull;
+            };
+            mix(&c.ps_lp, sizeof(c.ps_lp));
+            mix(&c.ps_n, sizeof(c.ps_n));
+            key ^= (h | 1ull) * 0x9e3779b97f4a7c15ull;
+        }
         auto it = c.graphs.find(key);
         if (it == c.graphs.end()) {
             if (c.graphs.size() >= 96) {  // bounded cache (prompt lengths vary)
@@ -605,6 +629,7 @@ void decode(Context &c, const int *tokens, const int *pos, const int *slot, int 
     }
     MW_HIP(hipEventRecord(c.ev_staging, st));
     c.staging_pending = true;
+    c.ps_fused = fuse && use_graph;
     c.n_logit_rows = n_logit_rows;
     c.tm.n_decode++;
     c.tm.decode_ms += now_ms() - t0;
@@ -674,10 +699,10 @@ LogitsParams make_logits_params(const Context &c, const whisper_full_params &p, 
 
 namespace {
 
-// run the rules + sampler for the listed decoders; row j of the launch serves decoders[idx[j]]
-void process_and_sample(Context &c, const whisper_full_params &params, float t_cur, const std::vector<int> &dec_idx,
-                        const std::vector<int> &logits_row, int n_samples, bool eot_forced_off) {
-    const double t0 = now_ms();
+// Row states + parameters of the rules + samplers for the listed decoders (row j serves decoders[idx[j]]), prepared BEFORE
+// the decode call that produces their logits so that they can travel in its step block and run inside its graph.
+void prepare_sample(Context &c, const whisper_full_params &params, float t_cur, const std::vector<int> &dec_idx,
+                    const std::vector<int> &logits_row, int n_samples) {
     const int n = (int)dec_idx.size();
     MW_CHECK(n > 0 && n <= LOGIT_ROWS, "sampler: row count");
     const Vocab &v = c.model.vocab;
@@ -693,13 +718,26 @@ void process_and_sample(Context &c, const whisper_full_params &params, float t_c
         s.seek_delta = d.seek_delta;
         for (int k = 0; k < n_samples; ++k) s.u[k] = std::generate_canonical<double, 53>(d.rng);
     }
-    LogitsParams lp = make_logits_params(c, params, t_cur, n_samples);
-    (void)eot_forced_off;
-    MW_HIP(hipMemcpyAsync(c.d_row_state, c.h_row_state, n * sizeof(LogitsRowState), hipMemcpyHostToDevice, c.st));
-    launch_process_logits(c.d_logits, v.n_vocab, c.d_suppress, lp, c.d_row_state, c.d_row_res, n, c.d_work, nullptr,
-                          nullptr, nullptr, c.st);
-    MW_HIP(hipMemcpyAsync(c.h_row_res, c.d_row_res, n * sizeof(LogitsRowResult), hipMemcpyDeviceToHost, c.st));
+    memset(&c.ps_lp, 0, sizeof(c.ps_lp));  // padding bytes are hashed into the graph key
+    c.ps_lp = make_logits_params(c, params, t_cur, n_samples);
+    c.ps_n = n;
+    c.ps_armed = true;
+    c.ps_fused = false;
+}
+
+// results of the prepared rows: enqueues the rules + samplers here unless the decode call already did (ps_fused)
+void process_and_sample(Context &c, const std::vector<int> &dec_idx) {
+    const double t0 = now_ms();
+    const int n = (int)dec_idx.size();
+    MW_CHECK(c.ps_armed && n == c.ps_n, "sampler: rows were not prepared");
+    if (!c.ps_fused) {
+        MW_HIP(hipMemcpyAsync(c.d_row_state, c.h_row_state, n * sizeof(LogitsRowState), hipMemcpyHostToDevice, c.st));
+        launch_process_logits(c.d_logits, c.model.vocab.n_vocab, c.d_suppress, c.ps_lp, c.d_row_state, c.d_row_res, n, c.d_work,
+                              nullptr, nullptr, nullptr, c.st);
+        MW_HIP(hipMemcpyAsync(c.h_row_res, c.d_row_res, n * sizeof(LogitsRowResult), hipMemcpyDeviceToHost, c.st));
+    }
     MW_HIP(hipStreamSynchronize(c.st));
+    c.ps_armed = c.ps_fused = false;
     check_mega(c);
     for (int r = 0; r < n; ++r) c.decoders[dec_idx[r]].sampled = c.h_row_res[r];
     c.tm.n_sample++;
@@ -927,11 +965,12 @@ int full(Context &c, whisper_full_params params, const float *samples, int n_sam
                 std::vector<int> pos(prompt.size()), slot(prompt.size(), 0);
                 for (size_t i = 0; i < prompt.size(); ++i) pos[i] = (int)i;
                 const int last = (int)prompt.size() - 1;
-                decode(c, prompt.data(), pos.data(), slot.data(), (int)prompt.size(), &last, 1);
                 // every decoder starts from decoder 0's distribution (kv_seq_cp(0, j) == shared index table)
                 std::vector<int> idx(n_decoders_cur), rows(n_decoders_cur, 0);
                 for (int j = 0; j < n_decoders_cur; ++j) idx[j] = j;
-                process_and_sample(c, params, t_cur, idx, rows, n_draw, fds > 0);
+                prepare_sample(c, params, t_cur, idx, rows, n_draw);
+                decode(c, prompt.data(), pos.data(), slot.data(), (int)prompt.size(), &last, 1);
+                process_and_sample(c, idx);
             }
             for (int i = 0, n_max = hp.n_text_ctx / 2 - 4; i < n_max; ++i) {
                 if (beam)
@@ -1051,8 +1090,9 @@ int full(Context &c, whisper_full_params params, const float *samples, int n_sam
                         bp.push_back(n_past);
                         bs.push_back(j);
                     }
+                    prepare_sample(c, params, t_cur, idx, rows, n_draw);
                     decode(c, bt.data(), bp.data(), bs.data(), (int)bt.size(), rows.data(), (int)rows.size());
-                    process_and_sample(c, params, t_cur, idx, rows, n_draw, fds > 0);
+                    process_and_sample(c, idx);
                 }
             }
             {

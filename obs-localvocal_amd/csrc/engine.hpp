@@ -78,6 +78,14 @@ struct Context {
     LogitsRowState *h_row_state = nullptr;
     LogitsRowResult *h_row_res = nullptr;
     int n_logit_rows = 0;
+    // rules + samplers of a step ride in the decode call that produces their logits: prepare_sample() fills the row
+    // states (they travel in the step block), decode() enqueues the four kernels and the result copy behind the logits
+    // projection inside the replayed graph, process_and_sample() then only waits and reads (one copy up, one graph
+    // launch, one copy down per beam step instead of three copies and five more launches)
+    bool fuse_sample = true;  // env MI355_WHISPER_NO_FUSED_SAMPLE
+    bool ps_armed = false, ps_fused = false;
+    int ps_n = 0;
+    LogitsParams ps_lp{};
     // ---- whisper_full state ----
     Decoder decoders[MAX_DECODERS];
     std::vector<Segment> result_all;
