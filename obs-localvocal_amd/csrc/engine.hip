@@ -137,6 +137,7 @@ std::unique_ptr<Context> create_context_impl(const unsigned char *data, size_t s
     MW_HIP(hipEventCreateWithFlags(&c->ev_staging, hipEventDisableTiming));
     MW_HIP(hipHostMalloc((void **)&c->h_row_state, LOGIT_ROWS * sizeof(LogitsRowState)));
     MW_HIP(hipHostMalloc((void **)&c->h_row_res, LOGIT_ROWS * sizeof(LogitsRowResult)));
+    MW_HIP(hipHostGetDevicePointer((void **)&c->d_row_res_host, c->h_row_res, 0));
     c->decoders[0].rng = std::mt19937(0);
     c->n_ctx_cur = (int)T;
     if (getenv("MI355_WHISPER_NO_GRAPH")) c->use_graphs = false;  // debugging aid: eager launches
@@ -555,9 +556,9 @@ void decode(Context &c, const int *tokens, const int *pos, const int *slot, int 
             gemv2(g);
         }
         if (fuse) {
-            launch_process_logits(c.d_logits, hp.n_vocab, c.d_suppress, c.ps_lp, d_rs_block, c.d_row_res, c.ps_n, c.d_work, nullptr,
-                                  nullptr, nullptr, st);
-            MW_HIP(hipMemcpyAsync(c.h_row_res, c.d_row_res, c.ps_n * sizeof(LogitsRowResult), hipMemcpyDeviceToHost, st));
+            // results (100 bytes per row, write-only in the kernel) are stored straight into pinned host memory: no copy node
+            launch_process_logits(c.d_logits, hp.n_vocab, c.d_suppress, c.ps_lp, d_rs_block, c.d_row_res_host, c.ps_n, c.d_work,
+                                  nullptr, nullptr, nullptr, st);
         }
     };
     const bool use_graph = c.use_graphs && c.prof_tag < 0;

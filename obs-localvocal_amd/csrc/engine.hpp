@@ -77,6 +77,7 @@ struct Context {
     int reorder_src[KV_SLOTS] = {0}, reorder_n_past = 0;
     LogitsRowState *h_row_state = nullptr;
     LogitsRowResult *h_row_res = nullptr;
+    LogitsRowResult *d_row_res_host = nullptr;  // device view of h_row_res: the fused sampler stores its results straight into it
     int n_logit_rows = 0;
     // rules + samplers of a step ride in the decode call that produces their logits: prepare_sample() fills the row
     // states (they travel in the step block), decode() enqueues the four kernels and the result copy behind the logits
