@@ -238,6 +238,52 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
     }
 }
 
+// epilogue shared by the bf16 kernels: one vector store of 4 consecutive output elements per MFMA tile and lane
+template <typename TOUT, int BM, bool TR, int WJ>
+__device__ __forceinline__ void gemm_bf16_epilogue(const GemmArgs &a, f32x4 (&acc)[4][WJ], TOUT *C, const float *bias, const float *R,
+                                                   int m0, int n0, int wr, int wc, int lane) {
+    constexpr int WCOLS = BM == 128 ? 64 : 32;
+    const int M = a.M, N = a.N;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < WJ; ++j) {
+            // TR: lane = (n = lane & 15, m = 4*(lane >> 4) + r); else lane = (m = lane & 15, n = 4*(lane >> 4) + r)
+            const int mb = m0 + wr * 64 + i * 16 + (TR ? (lane >> 4) * 4 : (lane & 15));
+            const int nb = n0 + wc * WCOLS + j * 16 + (TR ? (lane & 15) : (lane >> 4) * 4);
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = TR ? mb + r : mb, n = TR ? nb : nb + r;
+                float x = acc[i][j][r] * a.alpha;
+                if (bias) x += bias[min(n, N - 1)];
+                if (a.act == ACT_GELU) x = gelu_f(x);
+                if (R) x += R[(long)min(m, M - 1) * a.ldr + min(n, N - 1)];
+                v[r] = x;
+            }
+            TOUT *dst = TR ? C + (long)nb * a.ldc + mb : C + (long)mb * a.ldc + nb;
+            const bool full = TR ? (nb < N && mb + 3 < M) : (mb < M && nb + 3 < N);
+            if (full && (((uintptr_t)dst) % (4 * sizeof(TOUT))) == 0) {
+                if constexpr (sizeof(TOUT) == 4) {
+                    *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    __hip_bfloat16 h0 = __float2bfloat16(v[0]), h1 = __float2bfloat16(v[1]), h2 = __float2bfloat16(v[2]),
+                                   h3 = __float2bfloat16(v[3]);
+                    uint2 pk;
+                    pk.x = (unsigned)*reinterpret_cast<bf16_t *>(&h0) | ((unsigned)*reinterpret_cast<bf16_t *>(&h1) << 16);
+                    pk.y = (unsigned)*reinterpret_cast<bf16_t *>(&h2) | ((unsigned)*reinterpret_cast<bf16_t *>(&h3) << 16);
+                    *reinterpret_cast<uint2 *>(dst) = pk;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = TR ? mb + r : mb, n = TR ? nb : nb + r;
+                    if (m < M && n < N) store_out(TR ? C + (long)n * a.ldc + m : C + (long)m * a.ldc + n, v[r]);
+                }
+            }
+        }
+}
+
 // ---- bf16 path with 64-deep k-steps ----
 // Same tiling as gemm_nt_kernel<bf16> (128 or 64 x 128 tile, 4 waves, 16x16x32 MFMA) with twice the k-extent per
 // iteration: the loop is bound by the latency of the next tile's global loads (one barrier and one wait per
@@ -357,45 +403,91 @@ __global__ __launch_bounds__(256) void gemm_bf16_k64_kernel(GemmArgs a) {
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
     }
-    // epilogue: one vector store of 4 consecutive output elements per MFMA tile and lane
+    gemm_bf16_epilogue<TOUT, BM, TR, WJ>(a, acc, C, bias, R, m0, n0, wr, wc, lane);
+}
+
+// ---- bf16 path, operands loaded straight into LDS (global_load_lds, 16 bytes per lane) ----
+// Same tile, fragment reads, MFMA order and epilogue as gemm_bf16_k64_kernel; what changes is the staging: no register
+// ring, no ds_write pass (79 B/clk against 256 B/clk for the reads), no masks.  A wave-instruction of the LDS DMA writes
+// 64 x 16 bytes to a wave-uniform base + lane * 16, i.e. 8 tile rows of 128 bytes in row order; the XOR swizzle the
+// fragment reads expect (chunk c of row r at slot c ^ (r & 7)) is therefore applied to the SOURCE address: the lane that
+// fills slot s of row r loads global chunk s ^ (r & 7) — still whole 128-byte lines per 8 lanes.
+// Pipeline: GS LDS stages, the loads of step kt + GS - 1 are issued right after the barrier of step kt (every wave has
+// then finished reading that stage in step kt - 1); a step's data are complete for the whole workgroup after each
+// wave's counted `s_waitcnt vmcnt` (the DMAs of the two younger steps stay in flight) followed by that barrier — one
+// barrier per k-step, a raw s_barrier (__syncthreads() would drain the DMAs).  Steps beyond the last reload the last
+// tile into a free stage so that the count is the same in every iteration.  Needs K % 64 == 0 (no zero-fill of a tail).
+template <typename TOUT, int BM, bool TR>
+__global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(GemmArgs a) {
+    constexpr int BK = 64, RB = 128, TILE_A = BM * RB, TILE_W = 128 * RB, STAGE = TILE_A + TILE_W, GS = 4;
+    constexpr int WJ = BM == 128 ? 4 : 2, WCOLS = BM == 128 ? 64 : 32, QA = BM == 128 ? 4 : 2, LPS = QA + 4;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[GS * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = BM == 128 ? wave >> 1 : 0, wc = BM == 128 ? wave & 1 : wave;
+    const TileCoord tc = xcd_tile_coord(a.hb);
+    const int z0 = tc.z / a.nz1, z1 = tc.z % a.nz1;
+    const bf16_t *A = (const bf16_t *)a.A + z0 * a.sA0 + z1 * a.sA1;
+    const bf16_t *W = (const bf16_t *)a.W + z0 * a.sW0 + z1 * a.sW1;
+    TOUT *C = (TOUT *)a.C + z0 * a.sC0 + z1 * a.sC1;
+    const float *bias = a.bias ? a.bias + z0 * a.sB0 + z1 * a.sB1 : nullptr;
+    const float *R = a.R ? a.R + z0 * a.sR0 + z1 * a.sR1 : nullptr;
+    const int m0 = tc.tm * BM, n0 = tc.tn * BN;
+    const int M = a.M, N = a.N, K = a.K;
+    auto swz8 = [](int r, int c) { return r * RB + ((c ^ (r & 7)) << 4); };
+    // piece q of this wave: tile rows 8 * wave + 32 * q .. + 7; lane -> row lane >> 3, slot lane & 7, global chunk slot ^ (row & 7)
+    const bf16_t *ga[QA], *gw[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = 8 * wave + 32 * q + (lane >> 3), chk = (lane & 7) ^ (row & 7);
+        if (q < QA) ga[q] = A + (long)min(m0 + row, M - 1) * a.lda + chk * 8;
+        gw[q] = W + (long)min(n0 + row, N - 1) * a.ldw + chk * 8;
+    }
+    const int nk = K / BK;
+    using gptr_t = const __attribute__((address_space(1))) void *;
+    using lptr_t = __attribute__((address_space(3))) void *;
+    auto issue = [&](int kt, int stage) {
+        const long off = (long)min(kt, nk - 1) * BK;
+        unsigned char *sa = lds + stage * STAGE + (8 * wave) * RB, *sw = sa + TILE_A;  // wave-uniform
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (q < QA) __builtin_amdgcn_global_load_lds((gptr_t)(ga[q] + off), (lptr_t)(sa + 32 * q * RB), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(gw[q] + off), (lptr_t)(sw + 32 * q * RB), 16, 0, 0);
+        }
+    };
+    f32x4 acc[4][WJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < WJ; ++j) {
-            // TR: lane = (n = lane & 15, m = 4*(lane >> 4) + r); else lane = (m = lane & 15, n = 4*(lane >> 4) + r)
-            const int mb = m0 + wr * 64 + i * 16 + (TR ? (lane >> 4) * 4 : (lane & 15));
-            const int nb = n0 + wc * WCOLS + j * 16 + (TR ? (lane & 15) : (lane >> 4) * 4);
-            float v[4];
+        for (int j = 0; j < WJ; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = TR ? mb + r : mb, n = TR ? nb : nb + r;
-                float x = acc[i][j][r] * a.alpha;
-                if (bias) x += bias[min(n, N - 1)];
-                if (a.act == ACT_GELU) x = gelu_f(x);
-                if (R) x += R[(long)min(m, M - 1) * a.ldr + min(n, N - 1)];
-                v[r] = x;
-            }
-            TOUT *dst = TR ? C + (long)nb * a.ldc + mb : C + (long)mb * a.ldc + nb;
-            const bool full = TR ? (nb < N && mb + 3 < M) : (mb < M && nb + 3 < N);
-            if (full && (((uintptr_t)dst) % (4 * sizeof(TOUT))) == 0) {
-                if constexpr (sizeof(TOUT) == 4) {
-                    *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-                    __hip_bfloat16 h0 = __float2bfloat16(v[0]), h1 = __float2bfloat16(v[1]), h2 = __float2bfloat16(v[2]),
-                                   h3 = __float2bfloat16(v[3]);
-                    uint2 pk;
-                    pk.x = (unsigned)*reinterpret_cast<bf16_t *>(&h0) | ((unsigned)*reinterpret_cast<bf16_t *>(&h1) << 16);
-                    pk.y = (unsigned)*reinterpret_cast<bf16_t *>(&h2) | ((unsigned)*reinterpret_cast<bf16_t *>(&h3) << 16);
-                    *reinterpret_cast<uint2 *>(dst) = pk;
-                }
-            } else {
+    for (int u = 0; u < GS - 1; ++u) issue(u, u);
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        // this wave's DMAs of step kt are done when at most the 2 * LPS younger ones are outstanding ...
+        if constexpr (LPS == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // ... and every wave's are, behind the barrier; stage (kt - 1) % GS is free again
+        issue(kt + GS - 1, (kt + GS - 1) % GS);
+        const unsigned char *la = lds + (kt % GS) * STAGE, *lw = la + TILE_A;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = TR ? mb + r : mb, n = TR ? nb : nb + r;
-                    if (m < M && n < N) store_out(TR ? C + (long)n * a.ldc + m : C + (long)m * a.ldc + n, v[r]);
-                }
-            }
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[4], bfr[WJ];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8 *>(la + swz8(wr * 64 + i * 16 + fr, 4 * ks + fq));
+#pragma unroll
+            for (int j = 0; j < WJ; ++j) bfr[j] = *reinterpret_cast<const bf16x8 *>(lw + swz8(wc * WCOLS + j * 16 + fr, 4 * ks + fq));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < WJ; ++j)
+                    acc[i][j] = TR ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8b, af[i]),
+                                                                             __builtin_bit_cast(bf16x8b, bfr[j]), acc[i][j], 0, 0, 0)
+                                   : __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8b, bfr[j]),
+                                                                             __builtin_bit_cast(bf16x8b, af[i]), acc[i][j], 0, 0, 0);
         }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the reloads of the last tile: nothing may land in LDS after the kernel's waves move on
+    gemm_bf16_epilogue<TOUT, BM, TR, WJ>(a, acc, C, bias, R, m0, n0, wr, wc, lane);
 }
 
 }  // namespace
@@ -447,9 +539,25 @@ void launch_gemm(const GemmArgs &args, DType in, DType out, hipStream_t st) {
         else if (a.trans_c) hipLaunchKernelGGL((gemm_bf16_k64_kernel<TOv, BMv, true, false>), grid, dim3(256), 0, st, a);   \
         else hipLaunchKernelGGL((gemm_bf16_k64_kernel<TOv, BMv, false, false>), grid, dim3(256), 0, st, a);                 \
     } while (0)
+    // LDS-direct staging (experiment switch MI355_WHISPER_GEMM_GLDS=1|0; default set below)
+    static const char *glds_env = getenv("MI355_WHISPER_GEMM_GLDS");
+    const bool glds = (glds_env ? glds_env[0] == '1' : false) && in == DType::BF16 && a.K % 64 == 0 && a.K >= 256;
+#define GLDS_LAUNCH(TOv, BMv)                                                                                           \
+    do {                                                                                                                \
+        if (a.trans_c) hipLaunchKernelGGL((gemm_bf16_glds_kernel<TOv, BMv, true>), grid, dim3(256), 0, st, a);          \
+        else hipLaunchKernelGGL((gemm_bf16_glds_kernel<TOv, BMv, false>), grid, dim3(256), 0, st, a);                   \
+    } while (0)
     static const bool k32 = getenv("MI355_WHISPER_GEMM_K32") != nullptr;  // experiments: the 32-deep k-step kernel
     if (in == DType::F32 && out == DType::F32)
         hipLaunchKernelGGL((gemm_nt_kernel<float, float, 128>), grid, dim3(256), 0, st, a);
+    else if (glds && out == DType::F32 && bm64)
+        GLDS_LAUNCH(float, 64);
+    else if (glds && out == DType::F32)
+        GLDS_LAUNCH(float, 128);
+    else if (glds && out == DType::BF16 && bm64)
+        GLDS_LAUNCH(bf16_t, 64);
+    else if (glds && out == DType::BF16)
+        GLDS_LAUNCH(bf16_t, 128);
     else if (in == DType::BF16 && out == DType::F32 && bm64 && !k32)
         K64_LAUNCH(float, 64);
     else if (in == DType::BF16 && out == DType::F32 && !k32)
@@ -469,6 +577,7 @@ void launch_gemm(const GemmArgs &args, DType in, DType out, hipStream_t st) {
     else
         MW_CHECK(false, "gemm: unsupported dtype combination");
 #undef K64_LAUNCH
+#undef GLDS_LAUNCH
     MW_HIP(hipGetLastError());
 }
 
