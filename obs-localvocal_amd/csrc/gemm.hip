@@ -540,7 +540,7 @@ void launch_gemm(const GemmArgs &args, DType in, DType out, hipStream_t st) {
         else hipLaunchKernelGGL((gemm_bf16_k64_kernel<TOv, BMv, false, false>), grid, dim3(256), 0, st, a);                 \
     } while (0)
     // LDS-direct staging (experiment switch MI355_WHISPER_GEMM_GLDS=1|0; default set below)
-    static const char *glds_env = getenv("MI355_WHISPER_GEMM_GLDS");
+    const char *glds_env = getenv("MI355_WHISPER_GEMM_GLDS");  // read per launch: a test compares both staging schemes in one process
     const bool glds = (glds_env ? glds_env[0] == '1' : false) && in == DType::BF16 && a.K % 64 == 0 && a.K >= 256;
 #define GLDS_LAUNCH(TOv, BMv)                                                                                           \
     do {                                                                                                                \

@@ -102,6 +102,31 @@ def test_contexts_are_reentrant_across_threads(pkg, model_file):
     assert out == alone
 
 
+def test_unfused_sampler_and_lds_direct_gemm_give_the_same_results(pkg, model_file, monkeypatch):
+    # Two experiment switches select other kernels / launch structures of the SAME arithmetic:
+    #  * MI355_WHISPER_NO_FUSED_SAMPLE: rules + samplers as launches of their own behind the decode graph (the form the
+    #    bench's launch-by-launch roofline leg also runs) -> identical tokens, beam search included;
+    #  * MI355_WHISPER_GEMM_GLDS: encoder GEMM operands staged by global_load_lds instead of the register ring; both
+    #    accumulate the same k-steps in the same order -> bit-identical encoder output.
+    path = model_file("tiny.en", ftype=1, n_audio_layer=2, n_text_layer=2)
+    pcm = ggml_io.synth_pcm(11, 12.0)
+    base_tok, base_seg = _forced_tokens(pkg, path, pcm, 24, pkg.PRECISION_BF16, strategy=1, language="en")
+    monkeypatch.setenv("MI355_WHISPER_NO_FUSED_SAMPLE", "1")
+    tok, seg = _forced_tokens(pkg, path, pcm, 24, pkg.PRECISION_BF16, strategy=1, language="en")
+    monkeypatch.delenv("MI355_WHISPER_NO_FUSED_SAMPLE")
+    assert tok == base_tok and seg == base_seg and len(tok) >= 20
+    eng = pkg.Engine(path, precision=pkg.PRECISION_BF16)
+    try:
+        eng.mel(pcm)
+        ref = eng.encode(0).copy()
+        monkeypatch.setenv("MI355_WHISPER_GEMM_GLDS", "1")
+        got = eng.encode(0).copy()
+        monkeypatch.delenv("MI355_WHISPER_GEMM_GLDS")
+        assert np.isfinite(ref).all() and np.array_equal(got, ref)
+    finally:
+        eng.close()
+
+
 def test_stream_contexts_share_one_weight_upload(pkg, model_file, monkeypatch):
     # configs[3]: many streams per GPU, weights resident once.  mw_init_shared (and whisper_init_from_file on a file that
     # is already resident) gives a context of its own on the same weights; the weights outlive the context that uploaded
