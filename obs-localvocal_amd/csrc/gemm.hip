@@ -7,11 +7,12 @@
 // precompute.  Replaces the ggml mul_mat / conv_1d graph nodes whisper.cpp runs inside whisper_full
 // (/root/reference/src/whisper-utils/whisper-processing.cpp:218-219).
 //
-// Bound: MFMA.  bf16 path: 128x128x32 tile, 4 waves (2x2), each wave 4x4 tiles of
-// v_mfma_f32_16x16x32_bf16, operands staged global -> registers -> LDS (XOR-swizzled 64-byte rows so
-// ds_read_b128 fragment reads are conflict-free), double-buffered so the next tile's global loads are
-// in flight during the MFMAs.  fp32 path (bit-exact-token mode for tiny/base): same tiling on
-// v_mfma_f32_32x32x2_f32 (exact fp32 fma chain), LDS tile stored k-major.
+// Bound: MFMA (measured: per-launch fixed cost and staging).  bf16 path (gemm_bf16_k64_kernel): 128 (or 64)
+// x 128 x 64 tile, 4 waves, v_mfma_f32_16x16x32_bf16, operands staged global -> register ring -> LDS (XOR-swizzled
+// 128-byte rows: conflict-free ds_read_b128 fragment reads), tiles assigned in an XCD-aware order; an LDS-direct
+// (global_load_lds) variant of the same tile is kept as an experiment switch (gemm_bf16_glds_kernel).  fp32 path
+// (bit-exact-token mode for tiny/base, gemm_nt_kernel): 128x128x16 tile on v_mfma_f32_32x32x2_f32 (exact fp32 fma chain),
+// LDS tile stored k-major.
 #include "kernels.hpp"
 
 #include <hip/hip_bf16.h>
@@ -296,7 +297,6 @@ __device__ __forceinline__ void gemm_bf16_epilogue(const GemmArgs &a, f32x4 (&ac
 // workgroups per CU: better when a CU has several tiles to overlap (cross-K/V over 32 layers, fc1).
 template <typename TOUT, int BM, bool TR, bool PIN>
 __global__ __launch_bounds__(256) void gemm_bf16_k64_kernel(GemmArgs a) {
-    constexpr int SK = 1, grp = 0;  // (an in-workgroup k-split over two 4-wave groups was measured: no gain)
     constexpr int BK = 64, RB = 128, TILE = 128 * RB;
     constexpr int WJ = BM == 128 ? 4 : 2, WCOLS = BM == 128 ? 64 : 32, QA = BM == 128 ? 4 : 2;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * TILE];
@@ -323,8 +323,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_k64_kernel(GemmArgs a) {
         gw[q] = W + (long)min(n0 + row, N - 1) * a.ldw + chk * 8;
     }
     const int kchk = (tid & 7) * 8;  // k offset of this thread's chunks inside a k-step
-    const int nk_all = (K + BK - 1) / BK;
-    const int nk = (nk_all + SK - 1) / SK;  // k-steps of this group: its step kt is step kt * SK + grp of the product
+    const int nk = (K + BK - 1) / BK;
     // Register ring of NS k-steps: the loads of step kt + NS - 1 are issued while step kt is multiplied, so a load has
     // NS - 2 iterations (not one) to arrive before its tile goes to LDS.  The k-loop is unrolled by NS so that every
     // ring index is a constant; steps beyond nk reload the last tile (clamped) and store zeros: no branch in the loop.
@@ -339,8 +338,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_k64_kernel(GemmArgs a) {
     u32x4 ra[NS][QA], rw[NS][4];
     unsigned rm[NS];
     auto gload = [&](int kt, u32x4(&pa)[QA], u32x4(&pw)[4], unsigned &pm) {
-        const int ks_all = kt * SK + grp, kc = min(ks_all, nk_all - 1);
-        const bool ok = kt < nk && ks_all < nk_all && kc * BK + kchk < K;
+        const int kc = min(kt, nk - 1);
+        const bool ok = kt < nk && kc * BK + kchk < K;
         const long off = kc * BK + kchk < K ? (long)kc * BK : 0;
         unsigned m = ok ? 0xffffffffu : 0u;
         asm volatile("" : "+v"(m));
