@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Development tool: per-(kernel, grid) averages of every counter in a rocprofv3 --pmc counter_collection.csv, for the GEMM and
+fused-attention kernels of the encoder (usage: pmc_by_grid.py <counter_collection.csv>; see profiles/r01_pmc_encoder_mfma.txt)."""
 import collections, csv, sys, re
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(sys.argv[1])):
