@@ -503,10 +503,12 @@ void launch_gemm(const GemmArgs &args, DType in, DType out, hipStream_t st) {
     // note: lda < K is legal — the conv stem passes overlapping row views (row t = rows t-1..t+1)
     MW_CHECK(a.nz0 >= 1 && a.nz1 >= 1 && (long)a.nz0 * a.nz1 <= 65535, "gemm: batch count");
     if (a.R) MW_CHECK(a.ldr > 0, "gemm: residual stride");
-    // 64-row tiles when 128-row tiles would leave most of the 256 CUs without a tile (N = d projections at M = 1500)
+    // 64-row tiles when 128-row tiles would give the 256 CUs at most about one tile each (N = d and N = 2d at M = 1500)
     const long tiles128 = (long)ceil_div(a.N, BN) * ceil_div(a.M, 128) * a.nz0 * a.nz1;
     static const bool no64 = getenv("MI355_WHISPER_GEMM_BM128") != nullptr;  // experiments: 128-row tiles only
-    const bool bm64 = in == DType::BF16 && tiles128 < 200 && a.M > 64 && !no64;
+    static const char *bm64_env = getenv("MI355_WHISPER_GEMM_BM64_BELOW");  // experiments: tile-count threshold
+    static const long bm64_below = bm64_env ? atol(bm64_env) : 300;  // Q|K (240 tiles of 128 rows): 29.6 us, as 480 tiles of 64 rows 26.4; fc1 (480): 48 vs 56
+    const bool bm64 = in == DType::BF16 && tiles128 < bm64_below && a.M > 64 && !no64;
     dim3 grid(ceil_div(a.N, BN), ceil_div(a.M, bm64 ? 64 : 128), a.nz0 * a.nz1);
     MW_CHECK(grid.y <= 65535, "gemm: M too large for grid.y");
     {   // XCD-aware tile order (xcd_tile_coord): super-row height for which an XCD's share of the tiles is a compact rectangle
