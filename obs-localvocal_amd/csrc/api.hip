@@ -507,6 +507,7 @@ int mw_decode(struct whisper_context *ctx, const whisper_token *tokens, int n, i
         Context &c = *ctx->c;
         DeviceGuard g(c);
         if (n_past + n > c.model.hp.n_text_ctx) return -2;
+        c.ps_armed = c.ps_fused = false;  // stage call: logits only, no sampler rows ride along
         std::vector<int> pos(n), slot(n, seq), rows;
         for (int i = 0; i < n; ++i) pos[i] = n_past + i;
         for (int i = std::max(0, n - LOGIT_ROWS); i < n; ++i) rows.push_back(i);

@@ -826,6 +826,7 @@ int full(Context &c, whisper_full_params params, const float *samples, int n_sam
     const HParams &hp = model.hp;
     const double t_start = now_ms();
     if (params.logits_filter_callback || params.grammar_rules) return -10;
+    c.ps_armed = c.ps_fused = false;  // a call that failed between prepare_sample and process_and_sample leaves no armed rows behind
     auto &result_all = c.result_all;
     result_all.clear();
     if (n_samples > 0) pcm_to_mel(c, samples, n_samples, samples_on_device);
