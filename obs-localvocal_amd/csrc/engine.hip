@@ -134,6 +134,7 @@ std::unique_ptr<Context> create_context_impl(const unsigned char *data, size_t s
     dev_alloc(c->d_row_res, LOGIT_ROWS);
     MW_CHECK(TC >= LOGIT_ROWS + KV_SLOTS + 2, "n_text_ctx too small for the step block");
     MW_HIP(hipHostMalloc((void **)&c->h_ints, 4 * TC * sizeof(int)));
+    if (!getenv("MI355_WHISPER_NO_STEP_BEGIN")) MW_HIP(hipHostGetDevicePointer((void **)&c->h_ints_dev, c->h_ints, 0));
     MW_HIP(hipEventCreateWithFlags(&c->ev_staging, hipEventDisableTiming));
     MW_HIP(hipHostMalloc((void **)&c->h_row_state, LOGIT_ROWS * sizeof(LogitsRowState)));
     MW_HIP(hipHostMalloc((void **)&c->h_row_res, LOGIT_ROWS * sizeof(LogitsRowResult)));
@@ -447,8 +448,14 @@ void decode(Context &c, const int *tokens, const int *pos, const int *slot, int 
     // (~290 launches of 3-10 us kernels).  Per-step values (tokens, positions, slots) travel through
     // the pinned staging block and device arrays at fixed addresses, so the captured nodes stay valid.
     auto enqueue = [&]() {
-        MW_HIP(hipMemcpyAsync(c.d_tokens, hi, step_bytes, hipMemcpyHostToDevice, st));  // the whole step block in one copy
-        launch_kv_reorder_dev(c.d_kv_idx[c.kv_cur ^ 1], c.d_kv_idx[c.kv_cur], c.d_rows + LOGIT_ROWS, TC, st);  // no-op without an update
+        const bool step_begin = c.h_ints_dev != nullptr;
+        if (step_begin) {  // block from pinned host memory -> index-table update + embedding + device copy of the block, one launch
+            launch_step_begin(c.h_ints_dev, c.d_tokens, (int)((step_bytes + 3) / 4), TC, 3 * TC + LOGIT_ROWS, n, c.d_kv_idx[c.kv_cur ^ 1],
+                              c.d_kv_idx[c.kv_cur], m.tok_emb, wt, m.dec_pe, c.d_xd, d, st);
+        } else {
+            MW_HIP(hipMemcpyAsync(c.d_tokens, hi, step_bytes, hipMemcpyHostToDevice, st));  // the whole step block in one copy
+            launch_kv_reorder_dev(c.d_kv_idx[c.kv_cur ^ 1], c.d_kv_idx[c.kv_cur], c.d_rows + LOGIT_ROWS, TC, st);  // no-op without an update
+        }
         // launches of the profiled projection class are bracketed by HIP events (mw_profile_begin/end)
         auto gemv = [&](const GemvArgs &g) {
             const bool prof = g.tag == c.prof_tag && c.prof_n + 2 <= (int)c.prof_ev.size();
@@ -471,7 +478,7 @@ void decode(Context &c, const int *tokens, const int *pos, const int *slot, int 
                 gemv(g);
             }
         };
-        launch_embed(c.d_tokens, c.d_pos, m.tok_emb, wt, m.dec_pe, c.d_xd, n, d, st);
+        if (!step_begin) launch_embed(c.d_tokens, c.d_pos, m.tok_emb, wt, m.dec_pe, c.d_xd, n, d, st);
         const float qk_scale = powf(64.0f, -0.25f);
         int splits = std::min(CROSS_SPLITS_MAX, std::max(ceil_div(n_ctx, 256), ceil_div(n_ctx, 128)));
         if (const char *sv = getenv("MI355_WHISPER_CROSS_SPLITS")) splits = std::max(ceil_div(n_ctx, 256), std::min(CROSS_SPLITS_MAX, atoi(sv)));

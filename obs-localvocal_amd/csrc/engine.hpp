@@ -70,6 +70,7 @@ struct Context {
     LogitsRowResult *d_row_res = nullptr;
     // pinned host staging
     int *h_ints = nullptr;  // tokens | pos | slot | rows + index-table update (src[KV_SLOTS], n_past, flag): one copy per step
+    int *h_ints_dev = nullptr;  // device view of h_ints: the step's first kernel reads the block from there (env MI355_WHISPER_NO_STEP_BEGIN: copy node)
     hipEvent_t ev_staging = nullptr;  // recorded behind each decode launch: the staging block is free once it has passed
     bool staging_pending = false;
     // index-table update of the next decode call (kv_reorder defers it into that call's launch sequence)

@@ -139,6 +139,10 @@ struct BeamSrc {
 void launch_kv_reorder(const int *old_idx, int *new_idx, BeamSrc src, int n_past, int n_text_ctx, hipStream_t st);
 // same update with its arguments in device memory: args = src[KV_SLOTS], n_past, flag (0: nothing to do) — graph-replayable
 void launch_kv_reorder_dev(const int *old_idx, int *new_idx, const int *args, int n_text_ctx, hipStream_t st);
+// head of a decode call in one launch: step block from pinned host memory (device view) -> index-table update, token
+// embedding of n_rows rows, and the block's copy into device memory (block layout: engine.hip decode())
+void launch_step_begin(const int *h_block_dev, int *d_block, int n_ints, int n_text_ctx, int args_off, int n_rows, const int *old_idx,
+                       int *new_idx, const void *tok_emb, DType wt, const float *pos_emb, float *x, int d, hipStream_t st);
 
 // ------------------------------------------------------------------------------------------
 // the decoder stack of one step as a single persistent cooperative kernel (mega.hip): bf16 weights, <= 5 rows
