@@ -103,7 +103,7 @@ def test_contexts_are_reentrant_across_threads(pkg, model_file):
 
 
 def test_unfused_sampler_and_lds_direct_gemm_give_the_same_results(pkg, model_file, monkeypatch):
-    # Two experiment switches select other kernels / launch structures of the SAME arithmetic:
+    # Experiment switches that select other kernels / launch structures of the SAME arithmetic:
     #  * MI355_WHISPER_NO_FUSED_SAMPLE: rules + samplers as launches of their own behind the decode graph (the form the
     #    bench's launch-by-launch roofline leg also runs) -> identical tokens, beam search included;
     #  * MI355_WHISPER_GEMM_GLDS: encoder GEMM operands staged by global_load_lds instead of the register ring; both
@@ -115,6 +115,12 @@ def test_unfused_sampler_and_lds_direct_gemm_give_the_same_results(pkg, model_fi
     tok, seg = _forced_tokens(pkg, path, pcm, 24, pkg.PRECISION_BF16, strategy=1, language="en")
     monkeypatch.delenv("MI355_WHISPER_NO_FUSED_SAMPLE")
     assert tok == base_tok and seg == base_seg and len(tok) >= 20
+    #  * MI355_WHISPER_NO_STEP_BEGIN: copy node + index-table and embedding kernels instead of the one kernel that reads the
+    #    step block from pinned host memory -> identical tokens
+    monkeypatch.setenv("MI355_WHISPER_NO_STEP_BEGIN", "1")
+    tok, seg = _forced_tokens(pkg, path, pcm, 24, pkg.PRECISION_BF16, strategy=1, language="en")
+    monkeypatch.delenv("MI355_WHISPER_NO_STEP_BEGIN")
+    assert tok == base_tok and seg == base_seg
     eng = pkg.Engine(path, precision=pkg.PRECISION_BF16)
     try:
         eng.mel(pcm)
