@@ -2,7 +2,7 @@
 """Idle time between consecutive kernels of a rocprofv3 --kernel-trace CSV (development tool).
 
 usage: trace_gaps.py <kernel_trace.csv> [min_start_fraction | steps:A:B]
-(steps:A:B = from the A-th to the B-th embed_kernel launch, i.e. decode steps A..B-1 of the run)
+(steps:A:B = from the A-th to the B-th step_begin_kernel / embed_kernel launch, i.e. decode steps A..B-1 of the run)
 Prints, per (previous kernel -> next kernel) pair, the count and the mean / total gap, and the totals of busy and
 idle time, for the part of the trace after `min_start_fraction` of its span (default 0.5: skips model setup).
 """
@@ -23,7 +23,7 @@ def main():
     sel = sys.argv[2] if len(sys.argv) > 2 else "0.5"
     if sel.startswith("steps:"):
         a, b = (int(v) for v in sel.split(":")[1:3])
-        emb = [i for i, r in enumerate(rows) if r[2].startswith("embed_kernel")]
+        emb = [i for i, r in enumerate(rows) if r[2].startswith(("step_begin_kernel", "embed_kernel"))]  # first kernel of a decode call
         rows = rows[emb[a]:emb[b]]
     else:
         t0 = rows[0][0] + float(sel) * (rows[-1][1] - rows[0][0])
