@@ -44,6 +44,17 @@ int mw_hparams(struct whisper_context *ctx, int32_t out[11]);
 int mw_pcm_to_mel(struct whisper_context *ctx, const float *samples, int n_samples);
 /* same, PCM already resident in HBM (the timed region of bench.py starts here) */
 int mw_pcm_to_mel_device(struct whisper_context *ctx, const float *samples_device, int n_samples);
+/* The same log-mel for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that
+   forbid hipMalloc).  No counterpart in the reference.  Calls no hipMalloc / hipFree / allocating routine: the
+   intermediate rows and the global-maximum word live in a static __device__ array of the library (1.54 MB per GPU, held
+   until the process ends).  Input and output are the caller's device buffers: samples_device[n_samples] ->
+   mel_out_device[n_len][n_mel] fp32, frame-major (the engine's HBM layout, the transpose of mw_get_mel's),
+   n_len = (n_samples + 480000) / 160 written to *n_len_out.  Limits: n_samples <= 480640 (one 30 s window plus
+   LocalVocal's margins), mel_out_floats >= n_len * n_mel; beyond them the call fails (-100, mw_last_error says why).
+   The context's own mel state is left untouched.  Every call on one GPU shares that GPU's array: calls that overlap on
+   one GPU race (the call synchronises the context's stream before it returns). */
+int mw_pcm_to_mel_noalloc(struct whisper_context *ctx, const float *samples_device, int n_samples, float *mel_out_device,
+                          size_t mel_out_floats, int *n_len_out);
 int mw_mel_n_len(struct whisper_context *ctx);
 /* whisper_full (whisper-processing.cpp:218-219) with the PCM already resident in HBM on the context's device */
 int mw_full_device(struct whisper_context *ctx, struct whisper_full_params params, const float *samples_device,

@@ -101,7 +101,7 @@ EXPORTED_SYMBOLS = [
     "whisper_token_nosp", "whisper_token_not", "whisper_token_beg", "whisper_token_lang", "whisper_token_translate",
     "whisper_token_transcribe", "whisper_tokenize",
     "mw_full_device", "mw_profile_begin", "mw_profile_end",
-    "mw_init_from_file", "mw_init_from_buffer", "mw_init_shared", "mw_hparams", "mw_pcm_to_mel", "mw_pcm_to_mel_device", "mw_mel_n_len",
+    "mw_init_from_file", "mw_init_from_buffer", "mw_init_shared", "mw_hparams", "mw_pcm_to_mel", "mw_pcm_to_mel_device", "mw_pcm_to_mel_noalloc", "mw_mel_n_len",
     "mw_get_mel", "mw_encode", "mw_get_encoder_out", "mw_get_cross_kv", "mw_decode", "mw_get_logits", "mw_kv_clear",
     "mw_process_logits", "mw_get_timings", "mw_reset_timings", "mw_stream", "mw_synchronize",
     "mw_set_force_decode_steps", "mw_set_duplicate_class", "mw_bench_decode_step", "mw_bench_mel", "mw_bench_encode", "mw_last_error",
@@ -188,6 +188,7 @@ def lib():
     L.mw_hparams.argtypes = [P, IP]
     L.mw_pcm_to_mel.argtypes = [P, FP, C.c_int]
     L.mw_pcm_to_mel_device.argtypes = [P, P, C.c_int]
+    L.mw_pcm_to_mel_noalloc.argtypes = [P, P, C.c_int, P, C.c_size_t, C.POINTER(C.c_int)]
     L.mw_mel_n_len.argtypes = [P]
     L.mw_full_device.argtypes = [P, FullParams, P, C.c_int]
     L.mw_get_mel.argtypes = [P, FP]

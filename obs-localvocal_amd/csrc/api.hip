@@ -427,6 +427,18 @@ int mw_pcm_to_mel_device(struct whisper_context *ctx, const float *samples_devic
         return 0;
     });
 }
+int mw_pcm_to_mel_noalloc(struct whisper_context *ctx, const float *samples_device, int n_samples, float *mel_out_device,
+                          size_t mel_out_floats, int *n_len_out) {
+    if (!ctx || !ctx->c || !samples_device || !mel_out_device || n_samples <= 0) return -1;
+    return guarded("mw_pcm_to_mel_noalloc", [&]() {
+        Context &c = *ctx->c;
+        DeviceGuard g(c);
+        mel_noalloc(samples_device, n_samples, c.model.d_mel_tab, c.model.hp.n_mels, mel_out_device, mel_out_floats, n_len_out,
+                    c.device, c.st);
+        MW_HIP(hipStreamSynchronize(c.st));
+        return 0;
+    });
+}
 int mw_mel_n_len(struct whisper_context *ctx) { return ctx && ctx->c ? ctx->c->n_len : -1; }
 int mw_get_mel(struct whisper_context *ctx, float *out) {
     if (!ctx || !ctx->c || !out || !ctx->c->d_mel) return -1;

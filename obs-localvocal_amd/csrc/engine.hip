@@ -89,6 +89,7 @@ std::unique_ptr<Context> create_context_impl(const unsigned char *data, size_t s
     std::unique_ptr<Context> c(new Context());
     c->device = device;
     MW_HIP(hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking));
+    (void)mel_noalloc_init(device);  // device address of the allocation-free mel entry's scratch array, once per device
     if (share) c->model = share->model;
     else load_model(c->model, data, size, wt, c->st);
     const HParams &hp = c->model.hp;

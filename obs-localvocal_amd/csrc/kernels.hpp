@@ -39,6 +39,12 @@ void launch_mel_normalize(const float *d_raw, long raw_stride, float *d_out, lon
 // conv-stem operand: dst[s][1 + i][bin] = mel[s][seek + i][bin] (0 beyond n_len), rows 0 and n_rows+1 zero
 void launch_mel_window(const float *d_mel, long mel_stride, int n_len, int seek, int n_rows, int n_mel, int n_streams,
                        void *d_dst, long dst_stride, DType dt, hipStream_t st);
+// allocation-free log-mel (mw_pcm_to_mel_noalloc): intermediate rows + maximum word live in a file-scope __device__ array
+// of mel.hip; at most one 30 s window (+ LocalVocal's 2 x 320-sample margins) per call
+constexpr int MEL_NOALLOC_MAX_SAMPLES = 30 * 16000 + 640;
+float *mel_noalloc_init(int device);  // device must be current; returns the array's device address on it
+void mel_noalloc(const float *d_pcm, int n_samples, const MelTables *d_tab, int n_mel, float *d_out, size_t out_floats,
+                 int *n_len_out, int device, hipStream_t st);
 // whisper layout for the getter: out[bin][frame] <- in[frame][bin]
 void launch_transpose_f32(const float *d_in, float *d_out, int rows, int cols, hipStream_t st);
 

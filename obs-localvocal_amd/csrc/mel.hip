@@ -17,9 +17,24 @@
 
 #include <hip/hip_bf16.h>
 
+#include <mutex>
+
 namespace mw {
 
 namespace {
+
+// Scratch of the allocation-free log-mel entry point (mel_noalloc below; mw_pcm_to_mel_noalloc in
+// include/mi355_whisper.h): the global-maximum word (first 256-byte line) followed by the raw log10 mel rows of the
+// frames that overlap real samples.  One copy per GPU the library runs on, held until the process ends; every call on
+// a GPU uses that GPU's copy, so calls that overlap on one GPU race.  Host code never uses the array's name as an
+// address: mel_noalloc_init() asks the runtime for the device address once per device.
+constexpr int MEL_NOALLOC_MAX_ACTIVE = (MEL_NOALLOC_MAX_SAMPLES + MEL_N_FFT / 2) / MEL_HOP + 1;
+constexpr size_t MEL_NOALLOC_RAW_OFF = 64;  // floats: the raw rows start one 256-byte line behind the maximum word
+constexpr size_t MEL_NOALLOC_FLOATS = MEL_NOALLOC_RAW_OFF + (size_t)MEL_NOALLOC_MAX_ACTIVE * MEL_MAX_BINS;
+static __device__ __align__(256) float scratch[MEL_NOALLOC_FLOATS];  // 1.54 MB
+constexpr int MEL_NOALLOC_MAX_DEVICES = 64;
+float *g_scratch_ptr[MEL_NOALLOC_MAX_DEVICES] = {nullptr};
+std::mutex g_scratch_mutex;
 
 constexpr int FRAMES_PER_BLOCK = 16;
 constexpr int SPAN = (FRAMES_PER_BLOCK - 1) * MEL_HOP + MEL_N_FFT;  // 2800 samples
@@ -306,6 +321,45 @@ void launch_mel_window(const float *d_mel, long mel_stride, int n_len, int seek,
         hipLaunchKernelGGL(mel_window_kernel<bf16_t>, grid, dim3(256), 0, st, d_mel, mel_stride, n_len, seek, n_rows,
                            n_mel, (bf16_t *)d_dst, dst_stride);
     MW_HIP(hipGetLastError());
+}
+
+// The device address of `scratch` on `device` (which must be the current device): looked up once per device.
+float *mel_noalloc_init(int device) {
+    MW_CHECK(device >= 0 && device < MEL_NOALLOC_MAX_DEVICES, "mel_noalloc: device index out of range");
+    std::lock_guard<std::mutex> lk(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        int cur = -1;
+        MW_HIP(hipGetDevice(&cur));
+        MW_CHECK(cur == device, "mel_noalloc: the context's device is not current");
+        float *ptr = nullptr;
+        MW_HIP(hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch)));
+        MW_CHECK(ptr != nullptr, "mel_noalloc: no device address for the scratch array");
+        g_scratch_ptr[device] = ptr;
+    }
+    return g_scratch_ptr[device];
+}
+
+// log-mel of device-resident PCM into the caller's buffer d_out[n_len][n_mel]; the same two kernels as pcm_to_mel
+// (engine.hip) with the intermediate rows and the maximum word in the static scratch array.  Allocates nothing.
+void mel_noalloc(const float *d_pcm, int n_samples, const MelTables *d_tab, int n_mel, float *d_out, size_t out_floats,
+                 int *n_len_out, int device, hipStream_t st) {
+    MW_CHECK(d_pcm && d_out && n_samples > 0, "mel_noalloc: empty input");
+    MW_CHECK(n_samples <= MEL_NOALLOC_MAX_SAMPLES,
+             "mel_noalloc: more than 30 s + 640 samples of PCM (480640); the static scratch array holds one window");
+    MW_CHECK(n_mel > 0 && n_mel <= MEL_MAX_BINS, "mel_noalloc: bin count out of range");
+    const int n_len = (n_samples + 30 * 16000) / MEL_HOP;
+    const int n_active = std::min((n_samples + MEL_N_FFT / 2) / MEL_HOP + 1, n_len);
+    MW_CHECK(n_active <= MEL_NOALLOC_MAX_ACTIVE, "mel_noalloc: frame count exceeds the scratch array");
+    MW_CHECK(out_floats >= (size_t)n_len * n_mel, "mel_noalloc: output buffer smaller than n_len * n_mel floats");
+    float *ptr = mel_noalloc_init(device);
+    unsigned *gmax = reinterpret_cast<unsigned *>(ptr);
+    float *raw = ptr + MEL_NOALLOC_RAW_OFF;
+    // launch_mel_frames clears the maximum word (hipMemsetAsync on ptr); the raw rows of frames < n_active are all
+    // rewritten by this call and rows beyond are never read, so the previous call's contents cannot leak
+    launch_mel_frames(d_pcm, 0, n_samples, 1, d_tab, raw, (long)MEL_NOALLOC_MAX_ACTIVE * MEL_MAX_BINS, n_active, n_mel, gmax, st);
+    launch_mel_normalize(raw, (long)MEL_NOALLOC_MAX_ACTIVE * MEL_MAX_BINS, d_out, (long)n_len * n_mel, n_len, n_active, n_mel, 1,
+                         gmax, st);
+    if (n_len_out) *n_len_out = n_len;
 }
 
 void launch_transpose_f32(const float *d_in, float *d_out, int rows, int cols, hipStream_t st) {
