@@ -531,7 +531,27 @@ int mw_decode(struct whisper_context *ctx, const whisper_token *tokens, int n, i
         MW_HIP(hipStreamSynchronize(c.st));
         decode(c, tokens, pos.data(), slot.data(), n, rows.data(), (int)rows.size());
         MW_HIP(hipStreamSynchronize(c.st));
-        check_mega(c);
+        return 0;
+    });
+}
+int mw_decode_rows(struct whisper_context *ctx, const whisper_token *tokens, const int *pos, const int *seq, int n) {
+    if (!ctx || !ctx->c || !tokens || !pos || !seq || n <= 0 || n > LOGIT_ROWS) return -1;
+    return guarded("mw_decode_rows", [&]() {
+        Context &c = *ctx->c;
+        DeviceGuard g(c);
+        const int TC = c.model.hp.n_text_ctx;
+        for (int i = 0; i < n; ++i)
+            if (pos[i] < 0 || pos[i] >= TC || seq[i] < 0 || seq[i] >= MAX_DECODERS) return -2;
+        c.ps_armed = c.ps_fused = false;  // stage call: logits only
+        std::vector<int> rows(n);
+        for (int i = 0; i < n; ++i) rows[i] = i;
+        std::vector<int> idx((size_t)KV_SLOTS * TC);  // every sequence keeps its own keys/values (identity index table)
+        for (int s = 0; s < KV_SLOTS; ++s)
+            for (int p = 0; p < TC; ++p) idx[(size_t)s * TC + p] = s;
+        MW_HIP(hipMemcpyAsync(c.d_kv_idx[c.kv_cur], idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice, c.st));
+        MW_HIP(hipStreamSynchronize(c.st));
+        decode(c, tokens, pos, seq, n, rows.data(), n);
+        MW_HIP(hipStreamSynchronize(c.st));
         return 0;
     });
 }

@@ -1,0 +1,849 @@
+// dec_tile.hip — the beam step (<= 5 rows, bf16 weights) as straight-line matrix-core tile kernels for gfx950.
+//
+// With <= 5 rows every projection of a decode step is a weight-streaming matrix-vector product bound by latency, not
+// bandwidth: each kernel here is one short dependent link of the step's chain (8 per decoder layer + the logits
+// projection), written so that every global load is unconditional and issued before the first wait, whole cache
+// lines are read per instruction, and the rows ride in M of v_mfma_f32_16x16x32_bf16.  Replaces the decoder mul_mat /
+// attention graph whisper.cpp runs per token inside whisper_full
+// (/root/reference/src/whisper-utils/whisper-processing.cpp:218-219).  DESIGN.md §4 has the rules each
+// kernel follows and the measurements behind them.
+#include "kernels.hpp"
+
+#include <hip/hip_bf16.h>
+
+namespace mw {
+
+namespace {
+
+constexpr int MT = TILE_THREADS;
+
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+// total of the 16-lane DPP row a lane belongs to, in every lane of the row
+__device__ __forceinline__ float row16_sum(float v) {
+    v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);  // row_half_mirror
+    v = dpp_add<0x140>(v);  // row_mirror
+    return v;
+}
+__device__ __forceinline__ float wave_sum_all(float v) {
+    v = row16_sum(v);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+__device__ __forceinline__ float wave_max_all(float v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float gelu_f(float x) {
+    const float c = 0.79788456080286535587989211986876f, a = 0.044715f;
+    return 0.5f * x * (1.0f + tanhf(c * x * (1.0f + a * x * x)));
+}
+__device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ bf16_t to_bf16(float v) {
+    __hip_bfloat16 h = __float2bfloat16(v);
+    return *reinterpret_cast<bf16_t *>(&h);
+}
+__device__ __forceinline__ void unpack8(const uint4 &u, float (&f)[8]) {
+    f[0] = bf16_lo(u.x); f[1] = bf16_hi(u.x); f[2] = bf16_lo(u.y); f[3] = bf16_hi(u.y);
+    f[4] = bf16_lo(u.z); f[5] = bf16_hi(u.z); f[6] = bf16_lo(u.w); f[7] = bf16_hi(u.w);
+}
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+__device__ __forceinline__ uint4 ld_stream16(const void *p) {  // weights: read once per step
+    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+// agent-scope (write-through, sc1) stores: what other workgroups read after the next barrier
+__device__ __forceinline__ void st_agent(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(bf16_t *p, bf16_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not wait for outstanding
+// global loads (vmcnt), so weight prefetches stay in flight across the intra-phase synchronisations
+__device__ __forceinline__ void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+
+struct Proj {
+    const bf16_t *W;
+    const float *bias;
+    int N, K;
+};
+
+using bf16x8b = __attribute__((ext_vector_type(8))) __bf16;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using u32x4v = __attribute__((ext_vector_type(4))) unsigned;
+
+
+enum { EPI_QKV = 0, EPI_RES = 1, EPI_SCALE = 2, EPI_GELU_BF16 = 3, EPI_GELU_F32 = 4 };
+
+struct Epi {
+    // EPI_QKV
+    float *q;
+    bf16_t *kc, *vc;
+    const int *slot, *pos;
+    int TC, d;
+    float qk_scale;
+    // EPI_RES
+    const float *res;
+    float *xout;
+    // EPI_SCALE
+    float *fout;
+    float scale;
+    // EPI_GELU_BF16
+    bf16_t *hout;
+    int ldo;
+};
+
+__device__ __forceinline__ float wave_total(float v) {  // DPP reduction, result broadcast as a scalar
+    v = row16_sum(v);
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, false));  // row_bcast15
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xc, 0xf, false));  // row_bcast31
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+constexpr int LN_MAX_F4 = 5;  // float4 per lane of a LayerNorm row: K <= 1280
+
+
+// ---- the LayerNorm-fused projection as a kernel of its own: one 16-feature tile per workgroup, K <= 1280 ----
+// Same arithmetic as proj_phase<LN>, written so that the compiler emits straight-line code: every global load
+// is unconditional (clamped address, value selected afterwards) and issued before the first wait.  A load
+// under a predicate becomes a branch with `s_waitcnt vmcnt(0)` at its join; in proj_phase that put the weight
+// loads first and then five serialised (row, gamma, beta) round trips in front of the LayerNorm — 3 to 4 us
+// of a 5 us kernel (tools/microbench/mb_phases).
+template <int EPI>
+__device__ __forceinline__ void proj_finish(float v, int erow, int n_e, const Proj &p, const Epi &e, float res_e) {
+    if constexpr (EPI == EPI_QKV) {
+        const int d = e.d;
+        if (n_e < d) {
+            st_agent(e.q + (long)erow * d + n_e, v * e.qk_scale);
+        } else {
+            const long off = ((long)e.slot[erow] * e.TC + e.pos[erow]) * d;
+            if (n_e < 2 * d) st_agent(e.kc + off + (n_e - d), to_bf16(v * e.qk_scale));
+            else st_agent(e.vc + off + (n_e - 2 * d), to_bf16(v));
+        }
+    } else if constexpr (EPI == EPI_RES) {
+        st_agent(e.xout + (long)erow * p.N + n_e, v + res_e);
+    } else if constexpr (EPI == EPI_SCALE) {
+        st_agent(e.fout + (long)erow * p.N + n_e, v * e.scale);
+    } else if constexpr (EPI == EPI_GELU_BF16) {
+        st_agent(e.hout + (long)erow * e.ldo + n_e, to_bf16(gelu_f(v)));
+    } else {
+        st_agent(e.fout + (long)erow * e.ldo + n_e, gelu_f(v));
+    }
+}
+
+// The tile's weights (16 rows of K bf16, contiguous in memory) are loaded fully coalesced — wave w takes rows
+// 2w and 2w+1 as consecutive 1 KB pieces — and re-read from LDS in the MFMA B-fragment layout.  Loading the
+// fragments straight from global memory touches 64 cache lines per instruction (16 bytes of each) instead of
+// 8 and was 1.3-1.4 us slower per launch (tools/microbench/mb_latency, "B-fragment pattern").
+template <int NB, int EPI, int FR>
+__device__ __forceinline__ void proj_ln_tile(const Proj &p, const float *xin, const float *ln_w, const float *ln_b, int n, const Epi &e,
+                                             bf16_t *xs, bf16_t *wt, float *red, unsigned long long *stamp) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+    const int K = p.K, nf4 = K >> 2, ksteps = K >> 5, ldxs = K + 8, tile = blockIdx.x;
+    // ---- every global load of the kernel, in the order their values are needed ----
+    // (a wave without a row issues the same loads with every lane on one address: a single cache-line request each,
+    // still straight-line code — a branch around the loads made the compiler wait for them inside the branch)
+    const bool has_row = wave < n;
+    const float *xr = xin + (long)(has_row ? wave : 0) * K;
+    float4 v[LN_MAX_F4], gw[LN_MAX_F4], gb[LN_MAX_F4];
+#pragma unroll
+    for (int i = 0; i < LN_MAX_F4; ++i) v[i] = *reinterpret_cast<const float4 *>(xr + (has_row ? 4 * min(lane + 64 * i, nf4 - 1) : 0));
+#pragma unroll
+    for (int i = 0; i < LN_MAX_F4; ++i) {
+        const int c = has_row ? 4 * min(lane + 64 * i, nf4 - 1) : 0;
+        gw[i] = *reinterpret_cast<const float4 *>(ln_w + c);
+        gb[i] = *reinterpret_cast<const float4 *>(ln_b + c);
+    }
+    constexpr int RPW = FR / 8, WJ = (RPW * 160 + 63) / 64;  // weight rows per wave, load instructions per wave (K <= 1280)
+    constexpr int TL = FR > 16 ? FR / 16 : 1;                // 16-feature MFMA tiles per workgroup
+    uint4 w[WJ];
+    const int wpieces = RPW * (K >> 3);  // 16-byte pieces in the wave's row(s)
+    {
+        const bf16_t *wbase = p.W + (long)(tile * FR + RPW * wave) * K;
+#pragma unroll
+        for (int j = 0; j < WJ; ++j) w[j] = ld_stream16(wbase + 8 * min(lane + 64 * j, wpieces - 1));
+    }
+    const int et = tid >> 8, el = (tid & 255) >> 2, er = tid & 3, erow = 4 * (el >> 4) + er;  // finisher: tile, lane, register
+    const int n_e = tile * FR + min(16 * et + (el & 15), FR - 1);
+    const float bias_e = p.bias ? p.bias[n_e] : 0.0f;
+    long kv_off = 0;
+    if constexpr (EPI == EPI_QKV) {
+        const int rr = erow < n ? erow : 0;
+        kv_off = ((long)e.slot[rr] * e.TC + e.pos[rr]) * e.d;
+    }
+    // ---- LayerNorm of the wave's row (wave reductions only) -> bf16 in LDS ----
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_F4; ++i) s += lane + 64 * i < nf4 ? (v[i].x + v[i].y) + (v[i].z + v[i].w) : 0.0f;
+    const float mean = wave_total(s) * (1.0f / (float)K);
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_F4; ++i) {
+        const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
+        q += lane + 64 * i < nf4 ? (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3) : 0.0f;
+    }
+    const float rstd = rsqrtf(wave_total(q) * (1.0f / (float)K) + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < LN_MAX_F4; ++i) {
+        const int c = lane + 64 * i;
+        const float y0 = (v[i].x - mean) * rstd * gw[i].x + gb[i].x, y1 = (v[i].y - mean) * rstd * gw[i].y + gb[i].y;
+        const float y2 = (v[i].z - mean) * rstd * gw[i].z + gb[i].z, y3 = (v[i].w - mean) * rstd * gw[i].w + gb[i].w;
+        uint2 pk;
+        pk.x = (unsigned)to_bf16(y0) | ((unsigned)to_bf16(y1) << 16);
+        pk.y = (unsigned)to_bf16(y2) | ((unsigned)to_bf16(y3) << 16);
+        if (c < nf4 && wave < n) *reinterpret_cast<uint2 *>(xs + wave * ldxs + 4 * c) = pk;
+    }
+    if (stamp && tid == 0) stamp[0] = wall_clock64();
+    // ---- the wave's two weight rows -> LDS ----
+#pragma unroll
+    for (int j = 0; j < WJ; ++j) {
+        const int pc = lane + 64 * j, half = K >> 3;  // pieces per row
+        const int r = (pc >= half ? 1 : 0) + (pc >= 2 * half ? 1 : 0) + (pc >= 3 * half ? 1 : 0);
+        if (pc < wpieces) *reinterpret_cast<uint4 *>(wt + (RPW * wave + r) * ldxs + 8 * (pc - r * half)) = w[j];
+    }
+    lds_sync();
+    if (stamp && tid == 0) stamp[1] = wall_clock64();
+    // ---- matrix-core products ----
+    {
+        const bf16_t *arow = xs + (fr < n ? fr : 0) * ldxs + 8 * fq;  // rows >= n: any valid row, result ignored
+        const bf16_t *brow = wt + fr * ldxs + 8 * fq;
+        f32x4 acc[TL];
+#pragma unroll
+        for (int tl = 0; tl < TL; ++tl) acc[tl] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int step = wave + 8 * j, sc = min(step, ksteps - 1);
+            const uint4 af = *reinterpret_cast<const uint4 *>(arow + 32 * sc);
+#pragma unroll
+            for (int tl = 0; tl < TL; ++tl) {
+                uint4 wv = *reinterpret_cast<const uint4 *>(brow + 16 * tl * ldxs + 32 * sc);
+                if (step >= ksteps) wv = make_uint4(0, 0, 0, 0);
+                acc[tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8b, af), __builtin_bit_cast(bf16x8b, wv), acc[tl], 0,
+                                                                  0, 0);
+            }
+        }
+#pragma unroll
+        for (int tl = 0; tl < TL; ++tl) *reinterpret_cast<f32x4 *>(red + ((tl * 8 + wave) * 64 + lane) * 4) = acc[tl];
+    }
+    lds_sync();
+    if (stamp && tid == 0) stamp[2] = wall_clock64();
+    // ---- finish: fixed-order sum of the 8 partial tiles, bias, epilogue ----
+    if (et < TL && erow < n && 16 * et + (el & 15) < FR) {  // tile columns beyond FR come from unwritten LDS rows: ignored
+        float r = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r += red[((et * 8 + k) * 64 + el) * 4 + er];
+        r += bias_e;
+        if constexpr (EPI == EPI_QKV) {
+            const int d = e.d;
+            if (n_e < d) st_agent(e.q + (long)erow * d + n_e, r * e.qk_scale);
+            else if (n_e < 2 * d) st_agent(e.kc + kv_off + (n_e - d), to_bf16(r * e.qk_scale));
+            else st_agent(e.vc + kv_off + (n_e - 2 * d), to_bf16(r));
+        } else {
+            proj_finish<EPI>(r, erow, n_e, p, e, 0.0f);
+        }
+    }
+    if (stamp && tid == 0) stamp[3] = wall_clock64();
+}
+
+// ---- residual-class projection (attention outputs, fc2) as a kernel of its own: x rows are bf16, no LayerNorm ----
+// One 16-feature tile per workgroup; wave w owns the k-range [w*K/8, (w+1)*K/8) of all 16 weight rows and of the
+// x rows, in CH chunks of SPC MFMA steps.  Every load is issued up front, coalesced (a row segment of a chunk is
+// 64*SPC contiguous bytes); each chunk is transposed into the fragment layout through a wave-private LDS tile
+// (LDS operations of one wave execute in order: no barrier), so the only workgroup barrier is the one before
+// the 8 partial tiles are summed.
+template <int NB, int SPC, int CH, int FR>
+__device__ __forceinline__ void proj_res_tile(const Proj &p, const bf16_t *xin, int n, const Epi &e, bf16_t *lds_t, float *red,
+                                              unsigned long long *stamp) {
+    constexpr int KC = 32 * SPC, LDT = KC + 8, PPR = 4 * SPC;  // k per chunk, LDS row stride, 16-byte pieces per row segment
+    constexpr int XLD = CH * KC + 8, XPR = PPR * CH;           // the wave's x tile: row stride, pieces per row
+    constexpr int XI = (NB * XPR + 63) / 64;                   // x load instructions
+    constexpr int WI = (FR * PPR + 63) / 64;                   // weight load instructions per chunk (FR feature rows per workgroup)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+    const int K = p.K, tile = blockIdx.x, kw = wave * CH * KC;
+    u32x4v xv[XI];  // first-class vectors: as HIP uint4 structs this array was not split into registers and went through
+                    // LDS scratch, whose indexing reads the workgroup size from the dispatch packet in host memory (2-6 us)
+    uint4 w[CH][WI];
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+        const int pc = min(lane + 64 * i, NB * XPR - 1);
+        xv[i] = *reinterpret_cast<const u32x4v *>(xin + (long)min(pc / XPR, n - 1) * K + kw + 8 * (pc % XPR));
+    }
+    const int el = (tid & 255) >> 2, er = tid & 3, erow = 4 * (el >> 4) + er, n_e = tile * FR + min(el & 15, FR - 1);
+    const float res_e = e.res[(long)(erow < n ? erow : 0) * p.N + n_e];
+    const float bias_v = (p.bias ? p.bias : e.res)[n_e];  // unconditional load: a branch here would split the load block
+    const float bias_e = p.bias ? bias_v : 0.0f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int j = 0; j < WI; ++j) {
+            const int pc = min(lane + 64 * j, FR * PPR - 1);
+            w[c][j] = ld_stream16(p.W + (long)(tile * FR + pc / PPR) * K + kw + c * KC + 8 * (pc % PPR));
+        }
+    __builtin_amdgcn_sched_barrier(0);  // every load above is issued before anything below (no sinking next to the use)
+    bf16_t *wt = lds_t + wave * (16 * LDT + NB * XLD), *xt = wt + 16 * LDT;
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+        const int pc = min(lane + 64 * i, NB * XPR - 1);  // surplus lanes rewrite the last piece (same data): no predicate
+        *reinterpret_cast<u32x4v *>(xt + (pc / XPR) * XLD + 8 * (pc % XPR)) = xv[i];
+    }
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (stamp && tid == 0) stamp[0] = wall_clock64();
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+#pragma unroll
+        for (int j = 0; j < WI; ++j) {
+            const int pc = min(lane + 64 * j, FR * PPR - 1);  // surplus lanes rewrite the last piece
+            *reinterpret_cast<uint4 *>(wt + (pc / PPR) * LDT + 8 * (pc % PPR)) = w[c][j];
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < SPC; ++s2) {
+            const uint4 af = *reinterpret_cast<const uint4 *>(xt + (fr < n ? fr : 0) * XLD + c * KC + 32 * s2 + 8 * fq);
+            const uint4 bfr = *reinterpret_cast<const uint4 *>(wt + fr * LDT + 32 * s2 + 8 * fq);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8b, af), __builtin_bit_cast(bf16x8b, bfr), acc, 0, 0, 0);
+        }
+    }
+    if (stamp && tid == 0) stamp[1] = wall_clock64();
+    *reinterpret_cast<f32x4 *>(red + (wave * 64 + lane) * 4) = acc;
+    lds_sync();
+    if (stamp && tid == 0) stamp[2] = wall_clock64();
+    if (tid < 256 && erow < n && (el & 15) < FR) {  // tile columns beyond FR come from unwritten LDS rows: ignored
+        float r = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r += red[(k * 64 + el) * 4 + er];
+        st_agent(e.xout + (long)erow * p.N + n_e, r + bias_e + res_e);
+    }
+    if (stamp && tid == 0) stamp[3] = wall_clock64();
+}
+
+// ---- self-attention over the indirected KV cache: one workgroup per (row, head), thread = key.  Every
+// global load of the phase (index table, K row, the thread's V chunks) is issued before anything waits. ----
+__device__ __forceinline__ void st_out(bf16_t *p, float v) { st_agent(p, to_bf16(v)); }
+__device__ __forceinline__ void st_out(float *p, float v) { st_agent(p, v); }
+
+
+// ---- the logits projection (final LayerNorm + tied token embedding, N = n_vocab) as tile kernel ----
+// 128 vocabulary rows per workgroup: the LayerNorm of the <= 5 sampled rows is done once (wave w = row w) and
+// shared through LDS; wave w then owns the 16-feature tile w over the whole K and needs nobody else's sums (no
+// cross-wave reduction).  Its weights stream in chunks of 128 k (16 rows x 256 contiguous bytes per chunk, 4 loads
+// per lane) through a ring of LRING chunks in registers and a wave-private LDS tile (fragment layout).
+constexpr int LKC = 128, LLD = LKC + 8, LRING = 3;
+
+template <int NB, int NCH>
+__device__ __forceinline__ void logits_tile(const bf16_t *W, const float *xin, const int *d_rows, const float *ln_w, const float *ln_b,
+                                            float *out, long ldo, int n, int N, bf16_t *xs, bf16_t *wtile) {
+    constexpr int K = NCH * LKC, nf4 = K / 4, ldxs = K + 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+    const int f0 = (blockIdx.x * 8 + wave) * 16;  // first vocabulary row of the wave's tile
+    // ---- loads: the wave's LayerNorm row (or one address), then the first LRING weight chunks ----
+    const bool has_row = wave < n;
+    const float *xr = xin + (long)d_rows[has_row ? wave : 0] * K;
+    float4 v[LN_MAX_F4], gw[LN_MAX_F4], gb[LN_MAX_F4];
+#pragma unroll
+    for (int i = 0; i < LN_MAX_F4; ++i) v[i] = *reinterpret_cast<const float4 *>(xr + (has_row ? 4 * min(lane + 64 * i, nf4 - 1) : 0));
+#pragma unroll
+    for (int i = 0; i < LN_MAX_F4; ++i) {
+        const int c = has_row ? 4 * min(lane + 64 * i, nf4 - 1) : 0;
+        gw[i] = *reinterpret_cast<const float4 *>(ln_w + c);
+        gb[i] = *reinterpret_cast<const float4 *>(ln_b + c);
+    }
+    // weight piece (chunk c, load j): row = (lane + 64 j) >> 4, 16-byte column = (lane + 64 j) & 15
+    const bf16_t *wl[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int pc = lane + 64 * j;
+        wl[j] = W + (long)min(f0 + (pc >> 4), N - 1) * K + 8 * (pc & 15);  // rows beyond the vocabulary: clamped, never stored
+    }
+    uint4 w[NCH][4];
+#pragma unroll
+    for (int c = 0; c < LRING && c < NCH; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[c][j] = ld_stream16(wl[j] + c * LKC);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- LayerNorm of the wave's row -> bf16 in LDS ----
+    {
+        float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < LN_MAX_F4; ++i) s += lane + 64 * i < nf4 ? (v[i].x + v[i].y) + (v[i].z + v[i].w) : 0.0f;
+        const float mean = wave_total(s) * (1.0f / (float)K);
+        float q = 0.0f;
+#pragma unroll
+        for (int i = 0; i < LN_MAX_F4; ++i) {
+            const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
+            q += lane + 64 * i < nf4 ? (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3) : 0.0f;
+        }
+        const float rstd = rsqrtf(wave_total(q) * (1.0f / (float)K) + 1e-5f);
+#pragma unroll
+        for (int i = 0; i < LN_MAX_F4; ++i) {
+            const int c = lane + 64 * i;
+            const float y0 = (v[i].x - mean) * rstd * gw[i].x + gb[i].x, y1 = (v[i].y - mean) * rstd * gw[i].y + gb[i].y;
+            const float y2 = (v[i].z - mean) * rstd * gw[i].z + gb[i].z, y3 = (v[i].w - mean) * rstd * gw[i].w + gb[i].w;
+            uint2 pk;
+            pk.x = (unsigned)to_bf16(y0) | ((unsigned)to_bf16(y1) << 16);
+            pk.y = (unsigned)to_bf16(y2) | ((unsigned)to_bf16(y3) << 16);
+            if (c < nf4 && wave < n) *reinterpret_cast<uint2 *>(xs + wave * ldxs + 4 * c) = pk;
+        }
+    }
+    lds_sync();
+    // ---- the wave's tile over all of K: chunk c from the ring -> private LDS tile -> 4 MFMA steps ----
+    bf16_t *wt = wtile + wave * 16 * LLD;
+    const bf16_t *arow = xs + (fr < n ? fr : 0) * ldxs + 8 * fq;
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int pc = lane + 64 * j;
+            *reinterpret_cast<uint4 *>(wt + (pc >> 4) * LLD + 8 * (pc & 15)) = w[c][j];
+        }
+        if (c + LRING < NCH) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[c + LRING][j] = ld_stream16(wl[j] + (c + LRING) * LKC);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+            const uint4 af = *reinterpret_cast<const uint4 *>(arow + c * LKC + 32 * s2);
+            const uint4 bfr = *reinterpret_cast<const uint4 *>(wt + fr * LLD + 32 * s2 + 8 * fq);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8b, af), __builtin_bit_cast(bf16x8b, bfr), acc, 0, 0, 0);
+        }
+    }
+    // lane holds rows 4*fq + r of vocabulary entry f0 + fr
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * fq + r;
+        if (row < n && f0 + fr < N) out[(long)row * ldo + f0 + fr] = acc[r];
+    }
+}
+
+// ---- self-attention as a kernel of its own, straight-line: three dependent load levels and no more ----
+//   1. pos / slot of the row (scalar) and the thread's 8 query values        2. the index-table entries of its keys
+//   3. its 16-byte K and V chunks (thread (jj, e8): keys jj, jj+64, ...; 8 lanes cover a 128-byte head row, so an
+//      instruction reads whole cache lines)
+// Loads beyond the row's length are clamped to its last position (one line for the whole wave) and masked in the
+// arithmetic; nothing is predicated, so the compiler keeps each level's loads in one batch.  Probabilities stay
+// in registers (the thread that scored a key also weights its V chunk).
+template <typename OT>
+__device__ __forceinline__ void self_attn_lean(const float *q, const bf16_t *kc, const bf16_t *vc, const int *slot, const int *pos,
+                                               const int *kv_idx, OT *out, int H, int d, int TC, float *red, float *sm) {
+    constexpr int PVI = TILE_TC_MAX / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, jj = tid >> 3, e8 = tid & 7;
+    const int r = blockIdx.x / H, h = blockIdx.x - r * H;
+    const int np = pos[r] + 1;
+    const int *idx = kv_idx + (long)slot[r] * TC;
+    const float4 qa = *reinterpret_cast<const float4 *>(q + (long)r * d + h * 64 + e8 * 8);
+    const float4 qb = *reinterpret_cast<const float4 *>(q + (long)r * d + h * 64 + e8 * 8 + 4);
+    int iv[PVI];
+#pragma unroll
+    for (int i = 0; i < PVI; ++i) iv[i] = idx[min(jj + 64 * i, np - 1)];
+    uint4 kq[PVI], vq[PVI];
+#pragma unroll
+    for (int i = 0; i < PVI; ++i) {
+        const long off = ((long)iv[i] * TC + min(jj + 64 * i, np - 1)) * d + h * 64 + e8 * 8;
+        kq[i] = *reinterpret_cast<const uint4 *>(kc + off);
+        vq[i] = *reinterpret_cast<const uint4 *>(vc + off);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // the V loads stay in this batch (the scheduler would sink them next to their use)
+    float sc[PVI], mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < PVI; ++i) {
+        float f[8];
+        unpack8(kq[i], f);
+        float dot = qa.x * f[0];
+        dot = fmaf(qa.y, f[1], dot); dot = fmaf(qa.z, f[2], dot); dot = fmaf(qa.w, f[3], dot);
+        dot = fmaf(qb.x, f[4], dot); dot = fmaf(qb.y, f[5], dot); dot = fmaf(qb.z, f[6], dot); dot = fmaf(qb.w, f[7], dot);
+        dot += __shfl_xor(dot, 1);
+        dot += __shfl_xor(dot, 2);
+        dot += __shfl_xor(dot, 4);
+        sc[i] = jj + 64 * i < np ? dot : -INFINITY;
+        mx = fmaxf(mx, sc[i]);
+    }
+    mx = wave_max_all(mx);
+    if (lane == 0) sm[wave] = mx;
+    lds_sync();
+    mx = sm[0];
+#pragma unroll
+    for (int w = 1; w < MT / 64; ++w) mx = fmaxf(mx, sm[w]);
+    float o[8] = {0, 0, 0, 0, 0, 0, 0, 0}, psum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < PVI; ++i) {
+        const float w = jj + 64 * i < np ? expf(sc[i] - mx) : 0.0f;
+        psum += w;
+        float f[8];
+        unpack8(vq[i], f);
+#pragma unroll
+        for (int q8 = 0; q8 < 8; ++q8) o[q8] = fmaf(w, f[q8], o[q8]);
+    }
+    const float ws = wave_sum_all(e8 == 0 ? psum : 0.0f);  // the 8 lanes of a key hold the same weight: count it once
+#pragma unroll
+    for (int q8 = 0; q8 < 8; ++q8) {
+        float v = o[q8];
+        v += __shfl_xor(v, 8);
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        o[q8] = v;
+    }
+    if (lane == 0) sm[8 + wave] = ws;
+    if ((lane >> 3) == 0) {
+#pragma unroll
+        for (int q8 = 0; q8 < 8; ++q8) red[wave * 64 + e8 * 8 + q8] = o[q8];
+    }
+    lds_sync();
+    if (tid < 64) {
+        float sum = 0.0f, v = 0.0f;
+#pragma unroll
+        for (int w = 0; w < MT / 64; ++w) {
+            sum += sm[8 + w];
+            v += red[w * 64 + tid];
+        }
+        st_out(out + (long)r * d + h * 64 + tid, v / sum);
+    }
+}
+
+constexpr int CPART = 66;
+
+// tail of a cross-attention work item: count this split of head h; the last one to arrive combines the partial
+// softmax records of all splits (fixed split order) into the output rows
+template <int NB, typename OT>
+__device__ __forceinline__ void cross_count_and_combine(const float *part, OT *out, unsigned *head_cnt, float *sc, unsigned *flag,
+                                                        int n, int H, int d, int h, int splits) {
+    const int tid = threadIdx.x;
+        __syncthreads();  // partial stores acknowledged (vmcnt(0)) before this split is counted
+        if (tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(&head_cnt[h], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned last = old == (unsigned)splits - 1;
+            if (last) __hip_atomic_store(&head_cnt[h], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+            *flag = last;
+        }
+        lds_sync();
+        if (*flag) {  // every split of head h is in memory: combine in fixed split order
+            // one batch of unconditional loads per thread (row r, dim e): the splits' (max, sum) pairs — the same
+            // address for the 64 threads of a row — and the thread's own partial outputs; surplus slots repeat the
+            // last split and get weight zero
+            const int i = min(tid, NB * 64 - 1), r = min(i >> 6, n - 1), e = i & 63;
+            const float *pp = part + ((long)r * H + h) * splits * CPART;
+            float2 mlv[CROSS_SPLITS_MAX];
+            float ov[CROSS_SPLITS_MAX];
+#pragma unroll
+            for (int sidx = 0; sidx < CROSS_SPLITS_MAX; ++sidx) {
+                const float *ps = pp + min(sidx, splits - 1) * CPART;
+                mlv[sidx] = *reinterpret_cast<const float2 *>(ps);
+                ov[sidx] = ps[2 + e];
+            }
+            float M = -INFINITY;
+#pragma unroll
+            for (int sidx = 0; sidx < CROSS_SPLITS_MAX; ++sidx) M = fmaxf(M, sidx < splits ? mlv[sidx].x : -INFINITY);
+            float Lsum = 0.0f, acc = 0.0f;
+#pragma unroll
+            for (int sidx = 0; sidx < CROSS_SPLITS_MAX; ++sidx) {
+                const float mm = sidx < splits ? mlv[sidx].x : -INFINITY;
+                const float w = mm > -INFINITY ? expf(mm - M) : 0.0f;
+                Lsum += w * mlv[sidx].y;
+                acc += w * ov[sidx];
+            }
+            if (tid < NB * 64 && (tid >> 6) < n) st_out(out + (long)r * d + h * 64 + e, acc / Lsum);
+        }
+}
+
+
+// ---- cross-attention on the matrix cores (splits of at most 128 keys) ----
+// scores  S[row][key] = q[row] . K[key]:  A = q rows as bf16 (LDS), B = K rows straight from global memory (a lane's
+//         16 bytes are 8 consecutive head dims of its key), one 16-key tile per wave, 2 x v_mfma_f32_16x16x32_bf16;
+// P . V   O[row][dim] = sum_key P[row][key] V[key][dim]:  B needs 8 consecutive KEYS of one dim per lane, so the V
+//         tile is transposed on its way into LDS; wave w takes dims 16*(w&3).. and key half w>>2, 2 MFMAs each.
+constexpr int XK = 128;      // keys per split
+constexpr int XLDP = XK + 8; // LDS row stride (elements) of the [*][key] tiles: conflict-free 16-byte reads
+
+
+// ---- cross-attention on the matrix cores as a straight-line kernel of its own (one (head, split) per workgroup) ----
+// Same arithmetic as cross_attn_phase_mfma; differences: every global load is unconditional (keys beyond the split
+// are clamped to its last key and masked in the scores) and issued before anything else; K is loaded like V, 8 lanes
+// per 128-byte head row (whole cache lines per instruction), and re-read from LDS in the B-fragment layout; no LDS
+// zero-fill (operand rows beyond the real rows only feed result rows nobody reads).
+constexpr int XKD = 64 + 8;  // LDS row stride of the [key][dim] K tile
+
+template <int NB, typename OT>
+__device__ __forceinline__ void cross_attn_lean(const float *q, const bf16_t *kc, const bf16_t *vc, float *part, OT *out,
+                                                unsigned *head_cnt, int n, int H, int d, int n_ctx, int splits, int per, float *lds) {
+    bf16_t *qb = reinterpret_cast<bf16_t *>(lds);  // [16][72]    q rows
+    bf16_t *kt = qb + 16 * 72;                     // [XK][XKD]   K rows
+    bf16_t *vt = kt + XK * XKD;                    // [64][XLDP]  V transposed: [dim][key]
+    bf16_t *pb = vt + 64 * XLDP;                   // [16][XLDP]  probabilities
+    float *sc = reinterpret_cast<float *>(pb + 16 * XLDP);  // [NB][XK] scores; reused by the combine
+    float *red = sc + (NB * XK > 2 * NB * CROSS_SPLITS_MAX ? NB * XK : 2 * NB * CROSS_SPLITS_MAX);  // [8][64][4]
+    float *ml = red + 8 * 64 * 4;                  // [NB][2]
+    unsigned *flag = reinterpret_cast<unsigned *>(ml + NB * 2);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+    const int h = blockIdx.x / splits, sp = blockIdx.x - h * splits;
+    const int j0 = sp * per, nk = min(per, n_ctx - j0);  // may be <= 0 for a trailing split
+    const int last = max(nk - 1, 0) + min(j0, n_ctx - 1);  // a valid key for clamped loads
+    // ---- loads ----
+    const int qi = min(tid, NB * 64 - 1);
+    const float qv = q[(long)min(qi >> 6, n - 1) * d + h * 64 + (qi & 63)];
+    const int kk = tid >> 3, e8 = tid & 7;
+    u32x4v kq[2], vq[2];  // first-class vectors: component access stays in registers
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int key = kk + 64 * i;
+        const long off = (long)(key < nk ? j0 + key : last) * d + h * 64 + e8 * 8;
+        kq[i] = *reinterpret_cast<const u32x4v *>(kc + off);
+        vq[i] = *reinterpret_cast<const u32x4v *>(vc + off);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- stage q, K and V^T ----
+    qb[(qi >> 6) * 72 + (qi & 63)] = to_bf16(qv);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int key = kk + 64 * i;
+        *reinterpret_cast<u32x4v *>(kt + key * XKD + e8 * 8) = kq[i];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            vt[(e8 * 8 + 2 * c) * XLDP + key] = (bf16_t)(vq[i][c] & 0xffffu);
+            vt[(e8 * 8 + 2 * c + 1) * XLDP + key] = (bf16_t)(vq[i][c] >> 16);
+        }
+    }
+    lds_sync();
+    // ---- scores: wave w -> keys 16w .. 16w+15 ----
+    {
+        const int kkey = 16 * wave + fr;
+        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const uint4 af = *reinterpret_cast<const uint4 *>(qb + fr * 72 + 32 * s2 + 8 * fq);
+            const uint4 bfr = *reinterpret_cast<const uint4 *>(kt + kkey * XKD + 32 * s2 + 8 * fq);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8b, af), __builtin_bit_cast(bf16x8b, bfr), acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * fq + r;
+            if (row < NB) sc[row * XK + kkey] = kkey < nk ? acc[r] : -INFINITY;
+        }
+    }
+    lds_sync();
+    // ---- per-row softmax over the split (wave w: row w) ----
+    if (wave < NB) {
+        const int r = wave;
+        const float v0 = sc[r * XK + lane], v1 = sc[r * XK + 64 + lane];
+        const float mx = wave_max_all(fmaxf(v0, v1));
+        const float e0 = lane < nk ? expf(v0 - mx) : 0.0f, e1 = (64 + lane) < nk ? expf(v1 - mx) : 0.0f;
+        const float sum = wave_sum_all(e0 + e1);
+        pb[r * XLDP + lane] = to_bf16(e0);
+        pb[r * XLDP + 64 + lane] = to_bf16(e1);
+        if (lane == 0) {
+            ml[r * 2] = mx;
+            ml[r * 2 + 1] = sum;
+        }
+    }
+    lds_sync();
+    // ---- P . V ----
+    {
+        const int nt = wave & 3, kh = wave >> 2;
+        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int ks = 2 * kh + s2;
+            const uint4 af = *reinterpret_cast<const uint4 *>(pb + fr * XLDP + 32 * ks + 8 * fq);
+            const uint4 bfr = *reinterpret_cast<const uint4 *>(vt + (16 * nt + fr) * XLDP + 32 * ks + 8 * fq);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8b, af), __builtin_bit_cast(bf16x8b, bfr), acc, 0, 0, 0);
+        }
+        *reinterpret_cast<f32x4 *>(red + (wave * 64 + lane) * 4) = acc;
+    }
+    lds_sync();
+    if (tid < NB * 64) {
+        const int r = tid >> 6, e = tid & 63;
+        if (r < n) {
+            const int nt = e >> 4, src_lane = (r >> 2) * 16 + (e & 15), rr = r & 3;
+            const float v = red[(nt * 64 + src_lane) * 4 + rr] + red[((4 + nt) * 64 + src_lane) * 4 + rr];
+            float *pp = part + (((long)r * H + h) * splits + sp) * CPART;
+            st_agent(pp + 2 + e, v);
+            if (e == 0) {
+                st_agent(pp, ml[r * 2]);
+                st_agent(pp + 1, ml[r * 2 + 1]);
+            }
+        }
+    }
+    cross_count_and_combine<NB, OT>(part, out, head_cnt, sc, flag, n, H, d, h, splits);
+}
+
+
+
+template <int NB, int NCH>
+__global__ __launch_bounds__(MT) void logits_tile_kernel(const bf16_t *W, const float *xin, const int *d_rows, const float *ln_w,
+                                                                    const float *ln_b, float *out, long ldo, int n, int N) {
+    __shared__ __attribute__((aligned(16))) bf16_t xs[NB * (NCH * LKC + 8)];
+    __shared__ __attribute__((aligned(16))) bf16_t wtile[8 * 16 * LLD];
+    logits_tile<NB, NCH>(W, xin, d_rows, ln_w, ln_b, out, ldo, n, N, xs, wtile);
+}
+
+template <typename OT>
+__global__ __launch_bounds__(MT) void self_attn_lean_kernel(const float *q, const bf16_t *kc, const bf16_t *vc, const int *slot,
+                                                                       const int *pos, const int *kv_idx, OT *out, int H, int d, int TC) {
+    __shared__ __attribute__((aligned(16))) float red[8 * 64];
+    __shared__ float sm[16];
+    self_attn_lean<OT>(q, kc, vc, slot, pos, kv_idx, out, H, d, TC, red, sm);
+}
+
+
+template <int NB, int EPI, int FR>
+__global__ __launch_bounds__(MT) void proj_ln_tile_kernel(Proj p, const float *xin, const float *ln_w, const float *ln_b, int n,
+                                                                     Epi e) {
+    __shared__ __attribute__((aligned(16))) bf16_t xs[NB * (256 * LN_MAX_F4 + 8)];
+    __shared__ __attribute__((aligned(16))) bf16_t wt[FR * (256 * LN_MAX_F4 + 8)];
+    __shared__ __attribute__((aligned(16))) float red[(FR > 16 ? FR / 16 : 1) * 8 * 64 * 4];
+    proj_ln_tile<NB, EPI, FR>(p, xin, ln_w, ln_b, n, e, xs, wt, red, nullptr);
+}
+
+template <int NB, int SPC, int CH, int FR>
+__global__ __launch_bounds__(MT) void proj_res_tile_kernel(Proj p, const bf16_t *xin, int n, Epi e) {
+    __shared__ __attribute__((aligned(16))) bf16_t lds_t[8 * (16 * (32 * SPC + 8) + NB * (CH * 32 * SPC + 8))];
+    __shared__ __attribute__((aligned(16))) float red[8 * 64 * 4];
+    proj_res_tile<NB, SPC, CH, FR>(p, xin, n, e, lds_t, red, nullptr);
+}
+
+template <int NB, typename OT>
+__global__ __launch_bounds__(MT) void cross_attn_lean_kernel(const float *q, const bf16_t *kc, const bf16_t *vc, float *part,
+                                                                        OT *out, unsigned *head_cnt, int n, int H, int d, int n_ctx,
+                                                                        int splits, int per) {
+    __shared__ __attribute__((aligned(16))) float lds[(16 * 72 + XK * XKD + 64 * XLDP + 16 * XLDP) / 2 + NB * XK +
+                                                      2 * NB * CROSS_SPLITS_MAX + 8 * 64 * 4 + NB * 2 + 16];
+    cross_attn_lean<NB, OT>(q, kc, vc, part, out, head_cnt, n, H, d, n_ctx, splits, per, lds);
+}
+
+
+}  // namespace
+
+// Tile sizes per class (measured, DESIGN.md §4 rule 3): 8-feature tiles (twice the workgroups) for the projections of
+// at most d features (cross-q, attention outputs, fc2), 16 for qkv, 32-feature workgroups (two tiles, half the LayerNorm
+// passes) for fc1.
+void launch_proj_wg(const GemvArgs &a, hipStream_t st) {
+    MW_CHECK(a.x && a.W && a.out && a.n >= 1 && a.n <= 5, "proj_wg: 1..5 rows");
+    MW_CHECK(a.N % 32 == 0 && a.K % 32 == 0 && a.ldx == a.K && !a.d_rows, "proj_wg: shape");
+    const bool ln = a.ln_w != nullptr;
+    Proj p{(const bf16_t *)a.W, a.bias, a.N, a.K};
+    Epi e{};
+    const dim3 block(MT);
+#define MW_PROJ_LN(NBv, EPIv)                                                                                                       \
+    do {                                                                                                                            \
+        if (a.N <= 1280)                                                                                                            \
+            hipLaunchKernelGGL((proj_ln_tile_kernel<NBv, EPIv, 8>), dim3(a.N / 8), block, 0, st, p, (const float *)a.x, a.ln_w, a.ln_b, \
+                               a.n, e);                                                                                             \
+        else if (a.N > 4096)                                                                                                        \
+            hipLaunchKernelGGL((proj_ln_tile_kernel<NBv, EPIv, 32>), dim3(a.N / 32), block, 0, st, p, (const float *)a.x, a.ln_w,   \
+                               a.ln_b, a.n, e);                                                                                     \
+        else                                                                                                                        \
+            hipLaunchKernelGGL((proj_ln_tile_kernel<NBv, EPIv, 16>), dim3(a.N / 16), block, 0, st, p, (const float *)a.x, a.ln_w,   \
+                               a.ln_b, a.n, e);                                                                                     \
+    } while (0)
+#define MW_PROJ_LN_NB(EPIv)               \
+    do {                                   \
+        if (a.n == 1) MW_PROJ_LN(1, EPIv); \
+        else MW_PROJ_LN(5, EPIv);          \
+    } while (0)
+    if (ln) MW_CHECK(a.ln_b && a.K <= 256 * LN_MAX_F4, "proj_wg: LayerNorm classes need K <= 1280");
+    if (a.qkv) {
+        MW_CHECK(ln && a.N == 3 * a.K && a.ldo == a.K && a.kv_t == DType::BF16, "proj_wg: qkv class");
+        e.q = a.out; e.kc = (bf16_t *)a.kcache; e.vc = (bf16_t *)a.vcache; e.slot = a.d_slot; e.pos = a.d_pos; e.TC = a.n_text_ctx;
+        e.d = a.K; e.qk_scale = a.qk_scale;
+        MW_PROJ_LN_NB(EPI_QKV);
+    } else if (ln && a.act == ACT_GELU) {
+        MW_CHECK(!a.R, "proj_wg: fc1 class");
+        e.hout = (bf16_t *)a.out; e.fout = a.out; e.ldo = (int)a.ldo;
+        if (a.out_bf16) MW_PROJ_LN_NB(EPI_GELU_BF16);
+        else MW_PROJ_LN_NB(EPI_GELU_F32);
+    } else if (ln) {
+        MW_CHECK(!a.R && a.ldo == a.N && a.act == ACT_NONE, "proj_wg: cross-q class");
+        e.fout = a.out; e.scale = a.out_scale;
+        MW_PROJ_LN_NB(EPI_SCALE);
+    } else {
+        MW_CHECK(a.x_bf16 && a.R && a.ldo == a.N && a.act == ACT_NONE && a.out_scale == 1.0f, "proj_wg: residual class");
+        e.res = a.R; e.xout = a.out;
+        const int ch = a.K > 1280 ? 4 : 1, spc = a.K / (256 * ch);  // K = 8 waves x CH chunks x SPC steps x 32
+        MW_CHECK(a.K == 256 * ch * spc && spc >= 2 && spc <= 5, "proj_wg: residual class needs K = 256 * {1,4} * {2..5}");
+#define MW_RES(NBv, SPCv, CHv) \
+    hipLaunchKernelGGL((proj_res_tile_kernel<NBv, SPCv, CHv, 8>), dim3(a.N / 8), block, 0, st, p, (const bf16_t *)a.x, a.n, e)
+#define MW_RES_SPC(SPCv)                                    \
+    do {                                                     \
+        if (a.n == 1 && ch == 1) MW_RES(1, SPCv, 1);         \
+        else if (a.n == 1) MW_RES(1, SPCv, 4);               \
+        else if (ch == 1) MW_RES(5, SPCv, 1);                \
+        else MW_RES(5, SPCv, 4);                             \
+    } while (0)
+        switch (spc) {
+        case 2: MW_RES_SPC(2); break;
+        case 3: MW_RES_SPC(3); break;
+        case 4: MW_RES_SPC(4); break;
+        default: MW_RES_SPC(5); break;
+        }
+#undef MW_RES_SPC
+#undef MW_RES
+    }
+#undef MW_PROJ_LN_NB
+#undef MW_PROJ_LN
+    MW_HIP(hipGetLastError());
+}
+
+bool logits_tile_supported(const GemvArgs &a) {
+    const int nch = a.K / LKC;
+    return a.n >= 1 && a.n <= 5 && a.ln_w && a.ln_b && a.d_rows && a.K % LKC == 0 && a.ldx == a.K && !a.bias && !a.R &&
+           a.act == ACT_NONE && a.out_scale == 1.0f && (nch == 3 || nch == 4 || nch == 6 || nch == 8 || nch == 10);
+}
+
+void launch_logits_tile(const GemvArgs &a, hipStream_t st) {
+    MW_CHECK(logits_tile_supported(a), "logits_tile: shape");
+    const dim3 grid(ceil_div(a.N, 128)), block(MT);
+#define MW_LT(NBv, NCHv)                                                                                                     \
+    hipLaunchKernelGGL((logits_tile_kernel<NBv, NCHv>), grid, block, 0, st, (const bf16_t *)a.W, a.x, a.d_rows, a.ln_w, a.ln_b, \
+                       a.out, a.ldo, a.n, a.N)
+#define MW_LT_NB(NCHv)              \
+    do {                             \
+        if (a.n == 1) MW_LT(1, NCHv); \
+        else MW_LT(5, NCHv);          \
+    } while (0)
+    switch (a.K / LKC) {
+    case 3: MW_LT_NB(3); break;
+    case 4: MW_LT_NB(4); break;
+    case 6: MW_LT_NB(6); break;
+    case 8: MW_LT_NB(8); break;
+    default: MW_LT_NB(10); break;
+    }
+#undef MW_LT_NB
+#undef MW_LT
+    MW_HIP(hipGetLastError());
+}
+
+void launch_self_attn_wg(const float *q, const void *kcache, const void *vcache, const int *d_slot, const int *d_pos,
+                         const int *d_kv_idx, void *out, DType out_t, int n, int H, int d, int n_text_ctx, hipStream_t st) {
+    MW_CHECK(n >= 1 && H >= 1 && d == H * 64 && n_text_ctx <= TILE_TC_MAX, "self_attn_wg: shape");
+    if (out_t == DType::F32)
+        hipLaunchKernelGGL(self_attn_lean_kernel<float>, dim3(n * H), dim3(MT), 0, st, q, (const bf16_t *)kcache, (const bf16_t *)vcache,
+                           d_slot, d_pos, d_kv_idx, (float *)out, H, d, n_text_ctx);
+    else
+        hipLaunchKernelGGL(self_attn_lean_kernel<bf16_t>, dim3(n * H), dim3(MT), 0, st, q, (const bf16_t *)kcache, (const bf16_t *)vcache,
+                           d_slot, d_pos, d_kv_idx, (bf16_t *)out, H, d, n_text_ctx);
+    MW_HIP(hipGetLastError());
+}
+
+void launch_cross_attn_wg(const float *q, const void *kc, const void *vc, float *partial, void *out, DType out_t, unsigned *head_cnt,
+                          int n, int H, int d, int n_ctx, int splits, hipStream_t st) {
+    MW_CHECK(n >= 1 && n <= 5 && H >= 1 && d == H * 64, "cross_attn_wg: 1..5 rows, 64-wide heads");
+    MW_CHECK(splits >= 1 && splits <= CROSS_SPLITS_MAX, "cross_attn_wg: split count");
+    const int per = ceil_div(n_ctx, splits);
+    MW_CHECK(per <= XK, "cross_attn_wg: at most 128 keys per split");
+    const dim3 grid(H * splits), block(MT);
+#define MW_CROSS(NBv, OTv)                                                                                                \
+    hipLaunchKernelGGL((cross_attn_lean_kernel<NBv, OTv>), grid, block, 0, st, q, (const bf16_t *)kc, (const bf16_t *)vc, \
+                       partial, (OTv *)out, head_cnt, n, H, d, n_ctx, splits, per)
+    if (out_t == DType::F32) {
+        if (n == 1) MW_CROSS(1, float);
+        else MW_CROSS(5, float);
+    } else {
+        if (n == 1) MW_CROSS(1, bf16_t);
+        else MW_CROSS(5, bf16_t);
+    }
+#undef MW_CROSS
+    MW_HIP(hipGetLastError());
+}
+
+}  // namespace mw

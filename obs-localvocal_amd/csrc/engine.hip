@@ -33,25 +33,11 @@ const char *const k_non_speech[] = {
 
 Context::~Context() {
     (void)hipSetDevice(device);
-    if (d_mega_prof && !mega_prof_path.empty()) {  // developer aid: dump the last launch's phase stamps
-        const size_t n = (size_t)model.hp.n_text_layer * mega_grid * MEGA_PROF_STRIDE;
-        std::vector<unsigned long long> h(n);
-        if (hipDeviceSynchronize() == hipSuccess && hipMemcpy(h.data(), d_mega_prof, n * 8, hipMemcpyDeviceToHost) == hipSuccess) {
-            if (FILE *f = fopen(mega_prof_path.c_str(), "w")) {
-                fprintf(f, "%d %d %d\n", model.hp.n_text_layer, mega_grid, MEGA_PROF_STRIDE);
-                for (size_t i = 0; i < n; ++i) fprintf(f, "%llu%c", h[i], (i % MEGA_PROF_STRIDE == MEGA_PROF_STRIDE - 1) ? '\n' : ' ');
-                fclose(f);
-            }
-        }
-        (void)hipFree(d_mega_prof);
-    }
     void *ptrs[] = {d_pcm, d_mel_raw, d_mel, d_gmax, d_conv_in, d_x1, d_h, d_qk, d_vt, d_p, d_att, d_ff, d_enc_out, d_x,
                     d_s, d_cross, d_kself, d_vself, d_kv_idx[0], d_kv_idx[1], d_tokens, d_xd, d_q,
-                    d_attd, d_ffd, d_part, d_logits, d_work, d_suppress, d_row_state, d_row_res,
-                    d_mega_layers, d_mega_act, d_mega_sync, d_xout, d_head_cnt};
+                    d_attd, d_ffd, d_part, d_logits, d_work, d_suppress, d_row_state, d_row_res, d_head_cnt};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
-    if (h_mega_abort) (void)hipHostFree(h_mega_abort);
     if (h_ints) (void)hipHostFree(h_ints);
     if (ev_staging) (void)hipEventDestroy(ev_staging);
     if (h_row_state) (void)hipHostFree(h_row_state);
@@ -142,65 +128,20 @@ std::unique_ptr<Context> create_context_impl(const unsigned char *data, size_t s
     MW_HIP(hipHostGetDevicePointer((void **)&c->d_row_res_host, c->h_row_res, 0));
     c->decoders[0].rng = std::mt19937(0);
     c->n_ctx_cur = (int)T;
+    // the environment is read here, once per context, never on a launch path
     if (getenv("MI355_WHISPER_NO_GRAPH")) c->use_graphs = false;  // debugging aid: eager launches
     if (getenv("MI355_WHISPER_NO_FUSED_SAMPLE")) c->fuse_sample = false;  // rules + samplers as launches of their own
-    // the matrix-core projection variant measured ~5 % slower per window than the VALU one at 5 rows
-    // (profiles/r01_*): kept selectable for wider batches
     c->flash_attn = wt == DType::BF16 && getenv("MI355_WHISPER_NO_FLASH_ATTN") == nullptr;
-    c->mfma_proj = wt == DType::BF16 && getenv("MI355_WHISPER_MFMA_PROJ") != nullptr;
-    // persistent decode kernel: the whole decoder stack of a <= 5-row step in one cooperative launch
-    if (wt == DType::BF16 && TC <= (size_t)MEGA_TC_MAX && hp.n_text_state == hp.n_text_head * 64 && !getenv("MI355_WHISPER_NO_WG_ATTN")) {
+    {
+        const char *e = getenv("MI355_WHISPER_GEMM_GLDS");
+        c->gemm_glds = wt == DType::BF16 && e && e[0] == '1';
+    }
+    // the beam step on matrix-core tile kernels (dec_tile.hip); other shapes and fp32 use the VALU kernels of dec.hip
+    if (wt == DType::BF16 && TC <= (size_t)TILE_TC_MAX && hp.n_text_state == hp.n_text_head * 64 && hp.n_text_state % 256 == 0 &&
+        hp.n_text_state >= 512 && hp.n_text_state <= 1280) {
         dev_alloc(c->d_head_cnt, 64);
         MW_HIP(hipMemsetAsync(c->d_head_cnt, 0, 64 * sizeof(unsigned), c->st));
-        c->wg_attn = true;
-        c->proj_wg = hp.n_text_state % 128 == 0 && hp.n_text_state <= 1280 && !c->mfma_proj && getenv("MI355_WHISPER_NO_PROJ_WG") == nullptr;
-        // residual classes (attention outputs, fc2) on matrix-core tiles too: K = 8 waves x {1,4} chunks x 2..5 steps x 32
-        c->logits_tile = getenv("MI355_WHISPER_NO_LOGITS_TILE") == nullptr;
-        c->res_tile = c->proj_wg && hp.n_text_state % 256 == 0 && hp.n_text_state >= 512 && getenv("MI355_WHISPER_NO_RES_TILE") == nullptr;
-    }
-    // Measured slower than the graph-replayed step (cross-XCD hand-offs cost as much as a launch), so the
-    // persistent kernel is an opt-in experiment: MI355_WHISPER_MEGA=1
-    if (wt == DType::BF16 && !c->mfma_proj && getenv("MI355_WHISPER_MEGA")) {
-        std::string why;
-        const int grid = mega_max_grid(device);
-        const int dd = hp.n_text_state, HH = hp.n_text_head;
-        if (grid > 0 && mega_supported(dd, HH, (int)TC, (int)L, grid, &why)) {
-            const MegaActLayout lay = mega_act_layout(dd, HH);
-            c->mega_grid = grid;
-            c->mega_act_stride = lay.total;
-            dev_alloc(c->d_mega_act, lay.total * L);
-            dev_alloc(c->d_mega_sync, mega_sync_bytes() / sizeof(unsigned));
-            MW_HIP(hipMemsetAsync(c->d_mega_sync, 0, mega_sync_bytes(), c->st));
-            dev_alloc(c->d_xout, (size_t)8 * dd);
-            MW_HIP(hipHostMalloc((void **)&c->h_mega_abort, 64));
-            *c->h_mega_abort = 0;
-            std::vector<MegaLayerW> lw(L);
-            const size_t kv_layer = (size_t)KV_SLOTS * TC * dd * ws;
-            for (size_t l = 0; l < L; ++l) {
-                const DecLayer &e = c->model.dec[l];
-                MegaLayerW &w = lw[l];
-                w.qkv_w = (const bf16_t *)e.qkv_w; w.out_w = (const bf16_t *)e.out_w; w.cq_w = (const bf16_t *)e.cq_w;
-                w.co_w = (const bf16_t *)e.co_w; w.fc1_w = (const bf16_t *)e.fc1_w; w.fc2_w = (const bf16_t *)e.fc2_w;
-                w.qkv_b = e.qkv_b; w.out_b = e.out_b; w.cq_b = e.cq_b; w.co_b = e.co_b; w.fc1_b = e.fc1_b; w.fc2_b = e.fc2_b;
-                w.ln1_w = e.ln1_w; w.ln1_b = e.ln1_b; w.lnc_w = e.lnc_w; w.lnc_b = e.lnc_b; w.ln2_w = e.ln2_w; w.ln2_b = e.ln2_b;
-                const char *ck = (const char *)c->d_cross + l * 2 * T * dd * ws;
-                w.ck = (const bf16_t *)ck;
-                w.cv = (const bf16_t *)(ck + T * dd * ws);
-                w.ks = (bf16_t *)((char *)c->d_kself + l * kv_layer);
-                w.vs = (bf16_t *)((char *)c->d_vself + l * kv_layer);
-            }
-            dev_alloc(c->d_mega_layers, L);
-            MW_HIP(hipMemcpyAsync(c->d_mega_layers, lw.data(), L * sizeof(MegaLayerW), hipMemcpyHostToDevice, c->st));
-            MW_HIP(hipStreamSynchronize(c->st));  // lw is a stack-lifetime host buffer
-            c->use_mega = true;
-            if (const char *pp = getenv("MI355_WHISPER_MEGA_PROF")) {
-                c->mega_prof_path = pp;
-                dev_alloc(c->d_mega_prof, L * (size_t)grid * MEGA_PROF_STRIDE);
-                MW_HIP(hipMemsetAsync(c->d_mega_prof, 0, L * (size_t)grid * MEGA_PROF_STRIDE * 8, c->st));
-            }
-        } else {
-            log_msg(LOG_INFO, "mi355_whisper: persistent decode kernel not used (%s)\n", grid > 0 ? why.c_str() : "does not fit a CU");
-        }
+        c->tile_step = true;
     }
     MW_HIP(hipStreamSynchronize(c->st));
     log_msg(LOG_INFO, "mi355_whisper: %s (%zu params, %s weights, %.1f MB arena) on device %d (%s)\n",
@@ -262,6 +203,10 @@ void encode(Context &c, int seek) {
     hipStream_t st = c.st;
     const double t0 = now_ms();
     c.n_ctx_cur = n_ctx;
+    auto gemm = [&](GemmArgs &g, DType in, DType out, hipStream_t s) {
+        g.glds = c.gemm_glds ? 1 : 0;
+        launch_gemm(g, in, out, s);
+    };
     MW_CHECK(c.d_mel != nullptr, "encode called before any mel was computed");
     launch_mel_window(c.d_mel, 0, c.n_len, seek, T2, n_mel, 1, c.d_conv_in, (long)(T2 + 2) * n_mel, wt, st);
     {   // conv1 as a GEMM over the overlapping row view: output row t <- padded rows t, t+1, t+2
@@ -269,14 +214,14 @@ void encode(Context &c, int seek) {
         g.A = c.d_conv_in; g.lda = n_mel; g.W = m.conv1_w; g.ldw = 3 * n_mel;
         g.C = (char *)c.d_x1 + (size_t)d * ws; g.ldc = d;  // x1 row 0 stays zero (conv2's left pad)
         g.bias = m.conv1_b; g.M = T2; g.N = d; g.K = 3 * n_mel; g.act = ACT_GELU;
-        launch_gemm(g, wt, wt, st);
+        gemm(g, wt, wt, st);
     }
     {   // conv2, stride 2: output row t <- padded x1 rows 2t, 2t+1, 2t+2; + positional embedding
         GemmArgs g;
         g.A = c.d_x1; g.lda = 2 * d; g.W = m.conv2_w; g.ldw = 3 * d;
         g.C = c.d_x; g.ldc = d; g.bias = m.conv2_b; g.M = n_ctx; g.N = d; g.K = 3 * d; g.act = ACT_GELU;
         g.R = m.enc_pe; g.ldr = d;
-        launch_gemm(g, wt, DType::F32, st);
+        gemm(g, wt, DType::F32, st);
     }
     for (int l = 0; l < hp.n_audio_layer; ++l) {
         const EncLayer &e = m.enc[l];
@@ -285,13 +230,13 @@ void encode(Context &c, int seek) {
             GemmArgs g;  // Q | K
             g.A = c.d_h; g.lda = d; g.W = e.qk_w; g.ldw = d; g.C = c.d_qk; g.ldc = 2 * d; g.bias = e.qk_b;
             g.M = n_ctx; g.N = 2 * d; g.K = d;
-            launch_gemm(g, wt, wt, st);
+            gemm(g, wt, wt, st);
         }
         {
             GemmArgs g;  // V, stored transposed [d][tp]
             g.A = c.d_h; g.lda = d; g.W = e.v_w; g.ldw = d; g.C = c.d_vt; g.ldc = tp; g.bias = e.v_b;
             g.M = n_ctx; g.N = d; g.K = d; g.trans_c = 1;
-            launch_gemm(g, wt, wt, st);
+            gemm(g, wt, wt, st);
         }
         if (c.flash_attn) {
             launch_enc_flash_attn(c.d_qk, c.d_vt, c.d_att, n_ctx, tp, d, H, st);  // fused: scores never leave the chip
@@ -301,7 +246,7 @@ void encode(Context &c, int seek) {
                 g.A = c.d_qk; g.lda = 2 * d; g.W = (char *)c.d_qk + (size_t)d * ws; g.ldw = 2 * d;
                 g.C = c.d_s; g.ldc = tp; g.M = n_ctx; g.N = n_ctx; g.K = 64;
                 g.nz1 = H; g.sA1 = 64; g.sW1 = 64; g.sC1 = (long)n_ctx * tp;
-                launch_gemm(g, wt, DType::F32, st);
+                gemm(g, wt, DType::F32, st);
             }
             launch_softmax_rows(c.d_s, tp, c.d_p, tp, wt, (long)H * n_ctx, n_ctx, tp, 1.0f / sqrtf(64.0f), st);
             {
@@ -309,27 +254,27 @@ void encode(Context &c, int seek) {
                 g.A = c.d_p; g.lda = tp; g.W = c.d_vt; g.ldw = tp; g.C = c.d_att; g.ldc = d;
                 g.M = n_ctx; g.N = 64; g.K = tp;
                 g.nz1 = H; g.sA1 = (long)n_ctx * tp; g.sW1 = (long)64 * tp; g.sC1 = 64;
-                launch_gemm(g, wt, wt, st);
+                gemm(g, wt, wt, st);
             }
         }
         {
             GemmArgs g;  // x += att Wo^T + bo
             g.A = c.d_att; g.lda = d; g.W = e.out_w; g.ldw = d; g.C = c.d_x; g.ldc = d; g.bias = e.out_b;
             g.R = c.d_x; g.ldr = d; g.M = n_ctx; g.N = d; g.K = d;
-            launch_gemm(g, wt, DType::F32, st);
+            gemm(g, wt, DType::F32, st);
         }
         launch_layernorm(c.d_x, d, e.ln2_w, e.ln2_b, c.d_h, d, wt, n_ctx, d, st);
         {
             GemmArgs g;
             g.A = c.d_h; g.lda = d; g.W = e.fc1_w; g.ldw = d; g.C = c.d_ff; g.ldc = 4 * d; g.bias = e.fc1_b;
             g.M = n_ctx; g.N = 4 * d; g.K = d; g.act = ACT_GELU;
-            launch_gemm(g, wt, wt, st);
+            gemm(g, wt, wt, st);
         }
         {
             GemmArgs g;
             g.A = c.d_ff; g.lda = 4 * d; g.W = e.fc2_w; g.ldw = 4 * d; g.C = c.d_x; g.ldc = d; g.bias = e.fc2_b;
             g.R = c.d_x; g.ldr = d; g.M = n_ctx; g.N = d; g.K = 4 * d;
-            launch_gemm(g, wt, DType::F32, st);
+            gemm(g, wt, DType::F32, st);
         }
     }
     launch_layernorm(c.d_x, d, m.ln_post_w, m.ln_post_b, c.d_enc_out, d, wt, n_ctx, d, st);
@@ -340,12 +285,12 @@ void encode(Context &c, int seek) {
         g.A = c.d_enc_out; g.lda = d; g.W = m.ckv_w; g.ldw = d; g.C = c.d_cross; g.ldc = d;
         g.M = n_ctx; g.N = d; g.K = d; g.nz1 = L; g.sW1 = 2L * d * d; g.sC1 = per_layer;
         g.alpha = powf(64.0f, -0.25f);
-        launch_gemm(g, wt, wt, st);
+        gemm(g, wt, wt, st);
         GemmArgs v = g;
         v.W = (char *)m.ckv_w + (size_t)d * d * ws;
         v.C = (char *)c.d_cross + (size_t)hp.n_audio_ctx * d * ws;
         v.bias = m.ckv_b + d; v.sB1 = 2L * d; v.alpha = 1.0f;
-        launch_gemm(v, wt, wt, st);
+        gemm(v, wt, wt, st);
     }
     c.tm.n_encode++;
     c.tm.encode_ms += now_ms() - t0;
@@ -383,18 +328,6 @@ void kv_reorder(Context &c, const int *src, int n_past) {
     c.kv_cur ^= 1;
 }
 
-void check_mega(Context &c) {
-    if (!c.mega_launched || !c.h_mega_abort || *c.h_mega_abort == 0) return;
-    // a workgroup gave up waiting at a grid barrier: the step's results are invalid.  Reset the sync area
-    // and stop using the persistent kernel on this context.
-    *c.h_mega_abort = 0;
-    c.use_mega = false;
-    c.mega_epoch = 0;
-    MW_HIP(hipMemsetAsync(c.d_mega_sync, 0, mega_sync_bytes(), c.st));
-    MW_HIP(hipStreamSynchronize(c.st));
-    throw std::runtime_error("persistent decode kernel timed out at a grid barrier (results discarded; later steps use per-kernel launches)");
-}
-
 void decode(Context &c, const int *tokens, const int *pos, const int *slot, int n, const int *logit_rows,
             int n_logit_rows) {
     const Model &m = c.model;
@@ -411,19 +344,14 @@ void decode(Context &c, const int *tokens, const int *pos, const int *slot, int 
     }
     for (int i = 0; i < n_logit_rows; ++i) MW_CHECK(logit_rows[i] >= 0 && logit_rows[i] < n, "decode: bad logits row");
     hipStream_t st = c.st;
-    const bool res_tile = c.res_tile && n <= 5;
-    const bool mf = c.mfma_proj || res_tile;  // bf16 rows between attention / MLP kernels and the projections
+    const bool tile = c.tile_step && n <= 5;  // bf16 rows between attention / MLP kernels and the residual projections
+    const bool mf = tile;
     const DType act_t = mf ? DType::BF16 : DType::F32;
     const double t0 = now_ms();
     // the pinned staging block may still be read by the previous call's copy: wait for THAT call only (an event
     // recorded behind it), not for whatever else is in flight on the stream
     if (c.staging_pending) MW_HIP(hipEventSynchronize(c.ev_staging));
     c.staging_pending = false;
-    if (c.use_mega) {
-        MW_HIP(hipStreamSynchronize(st));  // the abort word of the previous persistent launch must have landed
-        flush_reorder(c);
-    }
-    check_mega(c);
     int *hi = c.h_ints;
     memcpy(hi, tokens, n * sizeof(int));
     memcpy(hi + TC, pos, n * sizeof(int));
@@ -437,7 +365,7 @@ void decode(Context &c, const int *tokens, const int *pos, const int *slot, int 
     size_t step_bytes = (size_t)(3 * TC + LOGIT_ROWS + KV_SLOTS + 2) * sizeof(int);
     // prepared rules + sampler rows (prepare_sample): appended to the step block, 8-byte aligned
     const size_t rs_off = (step_bytes + 7) / 8 * 8;
-    const bool fuse = c.ps_armed && c.fuse_sample && c.use_graphs && c.prof_tag < 0 && !c.use_mega && n_logit_rows > 0 &&
+    const bool fuse = c.ps_armed && c.fuse_sample && c.use_graphs && c.prof_tag < 0 && n_logit_rows > 0 &&
                       rs_off + (size_t)c.ps_n * sizeof(LogitsRowState) <= (size_t)4 * TC * sizeof(int);
     if (fuse) {
         memcpy((char *)hi + rs_off, c.h_row_state, (size_t)c.ps_n * sizeof(LogitsRowState));
@@ -461,13 +389,10 @@ void decode(Context &c, const int *tokens, const int *pos, const int *slot, int 
         auto gemv = [&](const GemvArgs &g) {
             const bool prof = g.tag == c.prof_tag && c.prof_n + 2 <= (int)c.prof_ev.size();
             if (prof) MW_HIP(hipEventRecord(c.prof_ev[c.prof_n++], st));
-            // LayerNorm-fused classes (qkv, cross-q, fc1) at <= 5 rows: one 16-feature tile per workgroup on the
-            // matrix cores, LayerNorm per wave (mega.hip); the residual classes stay on the VALU stream kernels,
-            // which spread their weight rows over 4x more workgroups (profiles/r01_*)
-            if (c.proj_wg && c.logits_tile && g.tag == GEMV_LOGITS && logits_tile_supported(g)) launch_logits_tile(g, st);
-            else if (c.proj_wg && n <= 5 && (g.ln_w || res_tile) && g.tag != GEMV_LOGITS) launch_proj_wg(g, st);
-            else if (c.mfma_proj && g.tag != GEMV_LOGITS) launch_gemv_mfma(g, st);  // matrix-core variant (dec_mfma.hip), opt-in
-            else launch_gemv(g, wt, st);      // VALU weight-streaming path (dec.hip)
+            // <= 5 rows on bf16 weights: matrix-core tile kernels (dec_tile.hip); else the VALU weight-streaming path (dec.hip)
+            if (c.tile_step && g.tag == GEMV_LOGITS && logits_tile_supported(g)) launch_logits_tile(g, st);
+            else if (tile && g.tag != GEMV_LOGITS) launch_proj_wg(g, st);
+            else launch_gemv(g, wt, st);
             if (prof) MW_HIP(hipEventRecord(c.prof_ev[c.prof_n++], st));
         };
         // measurement (mw_set_duplicate_class): the class's launches are issued twice; an in-place residual update writes
@@ -481,11 +406,10 @@ void decode(Context &c, const int *tokens, const int *pos, const int *slot, int 
         };
         if (!step_begin) launch_embed(c.d_tokens, c.d_pos, m.tok_emb, wt, m.dec_pe, c.d_xd, n, d, st);
         const float qk_scale = powf(64.0f, -0.25f);
-        int splits = std::min(CROSS_SPLITS_MAX, std::max(ceil_div(n_ctx, 256), ceil_div(n_ctx, 128)));
-        if (const char *sv = getenv("MI355_WHISPER_CROSS_SPLITS")) splits = std::max(ceil_div(n_ctx, 256), std::min(CROSS_SPLITS_MAX, atoi(sv)));
+        const int splits = std::min(CROSS_SPLITS_MAX, ceil_div(n_ctx, 128));
         const size_t kv_layer = (size_t)KV_SLOTS * TC * d * ws;
-        // <= 5 rows on bf16 K/V: workgroup-wide attention kernels (mega.hip), cross-attention combines in-kernel
-        const bool wg_attn = c.wg_attn && n <= 5 && ceil_div(n_ctx, splits) <= MEGA_CROSS_PER_MAX;
+        // <= 5 rows on bf16 K/V: workgroup-wide attention kernels (dec_tile.hip), cross-attention combines in-kernel
+        const bool wg_attn = tile && ceil_div(n_ctx, splits) <= 128;
         for (int l = 0; l < hp.n_text_layer; ++l) {
             const DecLayer &e = m.dec[l];
             {
@@ -570,36 +494,7 @@ void decode(Context &c, const int *tokens, const int *pos, const int *slot, int 
         }
     };
     const bool use_graph = c.use_graphs && c.prof_tag < 0;
-    if (c.use_mega && n <= 5 && c.prof_tag < 0) {
-        // persistent path: embed, ONE cooperative kernel for all layers, then the logits projection
-        MW_HIP(hipMemcpyAsync(c.d_tokens, hi, step_bytes, hipMemcpyHostToDevice, st));
-        launch_embed(c.d_tokens, c.d_pos, m.tok_emb, wt, m.dec_pe, c.d_xd, n, d, st);
-        MegaArgs a;
-        a.layers = c.d_mega_layers;
-        a.n_layer = hp.n_text_layer; a.d = d; a.H = H; a.TC = TC; a.n = n; a.n_ctx = n_ctx;
-        a.splits = std::max(1, std::min(CROSS_SPLITS_MAX, c.mega_grid / H));
-        a.per = ceil_div(n_ctx, a.splits);
-        while (a.per > MEGA_CROSS_PER_MAX) {  // more keys than threads: cannot happen at n_audio_ctx 1500 with >= 3 splits
-            a.splits += 1;
-            MW_CHECK(a.splits <= CROSS_SPLITS_MAX, "decode: audio context too long for the persistent kernel");
-            a.per = ceil_div(n_ctx, a.splits);
-        }
-        a.x0 = c.d_xd; a.act = c.d_mega_act; a.act_layer_stride = c.mega_act_stride; a.x_out = c.d_xout;
-        a.slot = c.d_slot; a.pos = c.d_pos; a.kv_idx = c.d_kv_idx[c.kv_cur];
-        a.sync = c.d_mega_sync; a.epoch_base = c.mega_epoch; a.qk_scale = powf(64.0f, -0.25f);
-        a.prof = c.d_mega_prof;
-        launch_decode_mega(a, c.mega_grid, st);
-        c.mega_epoch += (unsigned)mega_barriers_per_launch(hp.n_text_layer);
-        c.mega_launched = true;
-        MW_HIP(hipMemcpyAsync(c.h_mega_abort, c.d_mega_sync + MEGA_SYNC_ABORT_WORD, sizeof(unsigned), hipMemcpyDeviceToHost, st));
-        if (n_logit_rows > 0) {
-            GemvArgs g;
-            g.x = c.d_xout; g.ldx = d; g.n = n_logit_rows; g.W = m.tok_emb; g.N = hp.n_vocab; g.K = d;
-            g.ln_w = m.dec_ln_w; g.ln_b = m.dec_ln_b; g.out = c.d_logits; g.ldo = hp.n_vocab; g.d_rows = c.d_rows;
-            g.tag = GEMV_LOGITS;
-            launch_gemv(g, wt, st);
-        }
-    } else if (!use_graph) {
+    if (!use_graph) {
         enqueue();
     } else {
         uint64_t key = ((uint64_t)(c.dup_tag + 1) << 56) | ((uint64_t)n << 40) | ((uint64_t)n_logit_rows << 24) | ((uint64_t)n_ctx << 4) |
@@ -614,10 +509,18 @@ void decode(Context &c, const int *tokens, const int *pos, const int *slot, int 
             key ^= (h | 1ull) * 0x9e3779b97f4a7c15ull;
         }
         auto it = c.graphs.find(key);
-        if (it == c.graphs.end()) {
-            if (c.graphs.size() >= 96) {  // bounded cache (prompt lengths vary)
-                for (auto &kv : c.graphs) (void)hipGraphExecDestroy(kv.second);
-                c.graphs.clear();
+        if (it != c.graphs.end()) {  // most recently used last
+            auto pos = std::find(c.graph_lru.begin(), c.graph_lru.end(), key);
+            if (pos != c.graph_lru.end() && pos + 1 != c.graph_lru.end()) std::rotate(pos, pos + 1, c.graph_lru.end());
+        } else {
+            if (c.graphs.size() >= 96) {  // bounded cache (prompt lengths vary): evict the least recently used graph only
+                const uint64_t old = c.graph_lru.front();
+                c.graph_lru.erase(c.graph_lru.begin());
+                auto ot = c.graphs.find(old);
+                if (ot != c.graphs.end()) {
+                    (void)hipGraphExecDestroy(ot->second);
+                    c.graphs.erase(ot);
+                }
             }
             hipGraph_t graph = nullptr;
             MW_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
@@ -633,6 +536,7 @@ void decode(Context &c, const int *tokens, const int *pos, const int *slot, int 
             MW_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
             MW_HIP(hipGraphDestroy(graph));
             it = c.graphs.emplace(key, exec).first;
+            c.graph_lru.push_back(key);
         }
         MW_HIP(hipGraphLaunch(it->second, st));
     }
@@ -747,7 +651,6 @@ void process_and_sample(Context &c, const std::vector<int> &dec_idx) {
     }
     MW_HIP(hipStreamSynchronize(c.st));
     c.ps_armed = c.ps_fused = false;
-    check_mega(c);
     for (int r = 0; r < n; ++r) c.decoders[dec_idx[r]].sampled = c.h_row_res[r];
     c.tm.n_sample++;
     c.tm.sample_ms += now_ms() - t0;

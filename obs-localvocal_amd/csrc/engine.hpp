@@ -102,28 +102,15 @@ struct Context {
     int dup_tag = -1;  // measurement: launches of this class are issued twice inside the replayed step (mw_set_duplicate_class)
     std::vector<hipEvent_t> prof_ev;
     // captured decode steps, keyed by (rows, logits rows, audio ctx, index-table parity)
-    bool use_graphs = true;
-    bool flash_attn = false;  // fused encoder attention (bf16 only; env MI355_WHISPER_NO_FLASH_ATTN)
-    bool mfma_proj = false;  // decode projections on MFMA (bf16 weights only; env MI355_WHISPER_MFMA_PROJ)
+    // switches read ONCE at context creation from the environment (each has a parity test)
+    bool use_graphs = true;   // MI355_WHISPER_NO_GRAPH: eager launches instead of the replayed step
+    bool flash_attn = false;  // fused encoder attention (bf16 only; MI355_WHISPER_NO_FLASH_ATTN: QK^T, softmax, PV as three launches)
+    bool gemm_glds = false;   // MI355_WHISPER_GEMM_GLDS=1: encoder GEMM operands staged by global_load_lds
     std::unordered_map<uint64_t, hipGraphExec_t> graphs;
-    bool proj_wg = false;            // tile-per-workgroup MFMA projections for <= 5 rows (env MI355_WHISPER_PROJ_WG)
-    bool logits_tile = false;        // logits projection on matrix-core tiles (bf16 weights, <= 5 rows)
-    bool res_tile = false;           // residual-class projections on matrix-core tiles too (bf16 rows between the kernels)
-    bool wg_attn = false;            // workgroup-wide attention kernels for <= 5 rows (bf16 K/V)
+    std::vector<uint64_t> graph_lru;  // keys, least recently used first
+    // matrix-core tile kernels of the beam step (dec_tile.hip): bf16 weights, <= 5 rows, 64-wide heads, d % 256 == 0
+    bool tile_step = false;
     unsigned *d_head_cnt = nullptr;  // per-head arrival counters of the fused cross-attention combine
-    // persistent decode kernel (mega.hip): bf16 weights, <= 5 rows; opt-in experiment (env MI355_WHISPER_MEGA)
-    bool use_mega = false;
-    int mega_grid = 0;
-    MegaLayerW *d_mega_layers = nullptr;
-    char *d_mega_act = nullptr;
-    size_t mega_act_stride = 0;
-    unsigned *d_mega_sync = nullptr;
-    unsigned mega_epoch = 0;        // barriers completed on d_mega_sync so far
-    float *d_xout = nullptr;        // residual stream after the last layer
-    unsigned *h_mega_abort = nullptr;  // pinned copy of the kernel's abort word
-    bool mega_launched = false;
-    unsigned long long *d_mega_prof = nullptr;  // env MI355_WHISPER_MEGA_PROF=<file>: per-phase stamps of the last launch
-    std::string mega_prof_path;
 
     ~Context();
 };
@@ -138,8 +125,6 @@ void pcm_to_mel(Context &c, const float *pcm, int n_samples, bool pcm_on_device)
 void encode(Context &c, int seek);
 // decode n tokens; logits are produced for the rows listed in logit_rows (indices into the batch)
 void decode(Context &c, const int *tokens, const int *pos, const int *slot, int n, const int *logit_rows, int n_logit_rows);
-// throws if the last persistent-kernel launch aborted (call after a stream synchronisation)
-void check_mega(Context &c);
 void kv_clear(Context &c);
 void kv_reorder(Context &c, const int *src /*[MAX_DECODERS]*/, int n_past);
 int lang_auto_detect(Context &c, int offset_ms, float *probs);

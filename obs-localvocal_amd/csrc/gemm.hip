@@ -503,19 +503,16 @@ void launch_gemm(const GemmArgs &args, DType in, DType out, hipStream_t st) {
     // note: lda < K is legal — the conv stem passes overlapping row views (row t = rows t-1..t+1)
     MW_CHECK(a.nz0 >= 1 && a.nz1 >= 1 && (long)a.nz0 * a.nz1 <= 65535, "gemm: batch count");
     if (a.R) MW_CHECK(a.ldr > 0, "gemm: residual stride");
-    // 64-row tiles when 128-row tiles would give the 256 CUs at most about one tile each (N = d and N = 2d at M = 1500)
+    // 64-row tiles when 128-row tiles would give the 256 CUs at most about one tile each (N = d and N = 2d at M = 1500):
+    // Q|K (240 tiles of 128 rows) 29.6 us, as 480 tiles of 64 rows 26.4; fc1 (480 tiles): 48 vs 56
     const long tiles128 = (long)ceil_div(a.N, BN) * ceil_div(a.M, 128) * a.nz0 * a.nz1;
-    static const bool no64 = getenv("MI355_WHISPER_GEMM_BM128") != nullptr;  // experiments: 128-row tiles only
-    static const char *bm64_env = getenv("MI355_WHISPER_GEMM_BM64_BELOW");  // experiments: tile-count threshold
-    static const long bm64_below = bm64_env ? atol(bm64_env) : 300;  // Q|K (240 tiles of 128 rows): 29.6 us, as 480 tiles of 64 rows 26.4; fc1 (480): 48 vs 56
-    const bool bm64 = in == DType::BF16 && tiles128 < bm64_below && a.M > 64 && !no64;
+    const bool bm64 = in == DType::BF16 && tiles128 < 300 && a.M > 64;
     dim3 grid(ceil_div(a.N, BN), ceil_div(a.M, bm64 ? 64 : 128), a.nz0 * a.nz1);
     MW_CHECK(grid.y <= 65535, "gemm: M too large for grid.y");
     {   // XCD-aware tile order (xcd_tile_coord): super-row height for which an XCD's share of the tiles is a compact rectangle
-        static const bool no_remap = getenv("MI355_WHISPER_GEMM_NO_XCD") != nullptr;  // experiments: tile = blockIdx
         const long T = (long)grid.x * grid.y, G = T * grid.z, share = (G + 7) / 8;
         a.hb = 0;
-        if (!no_remap && G >= 16 && G < (1L << 31)) {
+        if (G >= 16 && G < (1L << 31)) {
             if (share >= T) {
                 a.hb = (int)grid.y;  // an XCD gets whole batch slices: any order inside a slice
             } else {
@@ -530,9 +527,8 @@ void launch_gemm(const GemmArgs &args, DType in, DType out, hipStream_t st) {
         }
     }
     // pinned load ring (one workgroup per CU) when the grid has at most one tile per CU anyway
-    static const char *pin_env = getenv("MI355_WHISPER_GEMM_PIN");  // experiments: 0 / 1 force the variant
     // (64-row tiles keep two workgroups per CU pinned or not: always pinned)
-    const bool pin = pin_env ? pin_env[0] == '1' : (bm64 || (long)grid.x * grid.y * grid.z <= 256);
+    const bool pin = bm64 || (long)grid.x * grid.y * grid.z <= 256;
 #define K64_LAUNCH(TOv, BMv)                                                                                                \
     do {                                                                                                                    \
         if (pin && a.trans_c) hipLaunchKernelGGL((gemm_bf16_k64_kernel<TOv, BMv, true, true>), grid, dim3(256), 0, st, a);  \
@@ -540,15 +536,13 @@ void launch_gemm(const GemmArgs &args, DType in, DType out, hipStream_t st) {
         else if (a.trans_c) hipLaunchKernelGGL((gemm_bf16_k64_kernel<TOv, BMv, true, false>), grid, dim3(256), 0, st, a);   \
         else hipLaunchKernelGGL((gemm_bf16_k64_kernel<TOv, BMv, false, false>), grid, dim3(256), 0, st, a);                 \
     } while (0)
-    // LDS-direct staging (experiment switch MI355_WHISPER_GEMM_GLDS=1|0; default set below)
-    const char *glds_env = getenv("MI355_WHISPER_GEMM_GLDS");  // read per launch: a test compares both staging schemes in one process
-    const bool glds = (glds_env ? glds_env[0] == '1' : false) && in == DType::BF16 && a.K % 64 == 0 && a.K >= 256;
+    // LDS-direct staging (GemmArgs::glds, set from the context's switch MI355_WHISPER_GEMM_GLDS read at context creation)
+    const bool glds = a.glds && in == DType::BF16 && a.K % 64 == 0 && a.K >= 256;
 #define GLDS_LAUNCH(TOv, BMv)                                                                                           \
     do {                                                                                                                \
         if (a.trans_c) hipLaunchKernelGGL((gemm_bf16_glds_kernel<TOv, BMv, true>), grid, dim3(256), 0, st, a);          \
         else hipLaunchKernelGGL((gemm_bf16_glds_kernel<TOv, BMv, false>), grid, dim3(256), 0, st, a);                   \
     } while (0)
-    static const bool k32 = getenv("MI355_WHISPER_GEMM_K32") != nullptr;  // experiments: the 32-deep k-step kernel
     if (in == DType::F32 && out == DType::F32)
         hipLaunchKernelGGL((gemm_nt_kernel<float, float, 128>), grid, dim3(256), 0, st, a);
     else if (glds && out == DType::F32 && bm64)
@@ -559,22 +553,14 @@ void launch_gemm(const GemmArgs &args, DType in, DType out, hipStream_t st) {
         GLDS_LAUNCH(bf16_t, 64);
     else if (glds && out == DType::BF16)
         GLDS_LAUNCH(bf16_t, 128);
-    else if (in == DType::BF16 && out == DType::F32 && bm64 && !k32)
-        K64_LAUNCH(float, 64);
-    else if (in == DType::BF16 && out == DType::F32 && !k32)
-        K64_LAUNCH(float, 128);
-    else if (in == DType::BF16 && out == DType::BF16 && bm64 && !k32)
-        K64_LAUNCH(bf16_t, 64);
-    else if (in == DType::BF16 && out == DType::BF16 && !k32)
-        K64_LAUNCH(bf16_t, 128);
     else if (in == DType::BF16 && out == DType::F32 && bm64)
-        hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, float, 64>), grid, dim3(256), 0, st, a);
+        K64_LAUNCH(float, 64);
     else if (in == DType::BF16 && out == DType::F32)
-        hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, float, 128>), grid, dim3(256), 0, st, a);
+        K64_LAUNCH(float, 128);
     else if (in == DType::BF16 && out == DType::BF16 && bm64)
-        hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, bf16_t, 64>), grid, dim3(256), 0, st, a);
+        K64_LAUNCH(bf16_t, 64);
     else if (in == DType::BF16 && out == DType::BF16)
-        hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, bf16_t, 128>), grid, dim3(256), 0, st, a);
+        K64_LAUNCH(bf16_t, 128);
     else
         MW_CHECK(false, "gemm: unsupported dtype combination");
 #undef K64_LAUNCH

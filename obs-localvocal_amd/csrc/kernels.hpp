@@ -68,6 +68,7 @@ struct GemmArgs {
     int act = ACT_NONE;
     int trans_c = 0;
     int hb = 0;  // set by launch_gemm: M-tiles per super-row of the XCD-aware tile order (0: tile = blockIdx)
+    int glds = 0;  // bf16: stage operands with global_load_lds instead of the register ring (Context::gemm_glds)
 };
 // in: element type of A and W; out: element type of C
 void launch_gemm(const GemmArgs &a, DType in, DType out, hipStream_t st);
@@ -123,12 +124,10 @@ struct GemvArgs {
     const int *d_slot = nullptr, *d_pos = nullptr;
     int n_text_ctx = 0;
     const int *d_rows = nullptr;  // optional row gather: use x row d_rows[i] for output row i
-    // bf16 matrix-core path only (dec_mfma.hip): activations already bf16 (direct classes) / bf16 output
+    // bf16 matrix-core tile kernels only (dec_tile.hip): activations already bf16 (residual classes) / bf16 output
     int x_bf16 = 0, out_bf16 = 0;
 };
 void launch_gemv(const GemvArgs &a, DType wt, hipStream_t st);
-// bf16 weights, <= 8 rows per pass on v_mfma_f32_16x16x32_bf16 (same contract as launch_gemv)
-void launch_gemv_mfma(const GemvArgs &a, hipStream_t st);
 
 // self-attention of n query rows over the indirected cache: row i attends positions 0..pos[i] of
 // logical sequence slot[i]; position p of sequence s lives in physical slot kv_idx[s][p].
@@ -151,56 +150,10 @@ void launch_step_begin(const int *h_block_dev, int *d_block, int n_ints, int n_t
                        int *new_idx, const void *tok_emb, DType wt, const float *pos_emb, float *x, int d, hipStream_t st);
 
 // ------------------------------------------------------------------------------------------
-// the decoder stack of one step as a single persistent cooperative kernel (mega.hip): bf16 weights, <= 5 rows
+// the beam step's matrix-core tile kernels (dec_tile.hip): bf16 weights, <= 5 rows
 // ------------------------------------------------------------------------------------------
-constexpr int MEGA_THREADS = 512;
-constexpr int MEGA_XS_BYTES = 52 * 1024;  // LDS staging of the bf16 activation rows (5 x (5120 + 8) x 2 bytes)
-constexpr int MEGA_PROF_STRIDE = 48;     // developer stamps per (layer, workgroup)
-constexpr int MEGA_TC_MAX = 448;         // text positions one self-attention pass covers (thread = key)
-constexpr int MEGA_CROSS_PER_MAX = 256;  // audio keys per cross-attention split
-
-struct MegaLayerW {  // one decoder layer, device pointers (array lives in device memory)
-    const bf16_t *qkv_w, *out_w, *cq_w, *co_w, *fc1_w, *fc2_w;
-    const float *qkv_b, *out_b, *cq_b, *co_b, *fc1_b, *fc2_b;
-    const float *ln1_w, *ln1_b, *lnc_w, *lnc_b, *ln2_w, *ln2_b;
-    const bf16_t *ck, *cv;  // this stream's cross K / V [n_audio_ctx][d]
-    bf16_t *ks, *vs;        // self K / V cache [KV_SLOTS][n_text_ctx][d]
-};
-
-// byte offsets inside one layer's slice of the activation arena; every buffer is written once per launch
-struct MegaActLayout {
-    size_t xa, xb, xc, q1, q2, at1, at2, ffd, part, total;
-};
-__host__ __device__ inline MegaActLayout mega_act_layout(int d, int H) {
-    MegaActLayout l;
-    const size_t rows = 8, f = rows * (size_t)d * 4, h = rows * (size_t)d * 2;
-    size_t o = 0;
-    l.xa = o; o += f;
-    l.xb = o; o += f;
-    l.xc = o; o += f;
-    l.q1 = o; o += f;
-    l.q2 = o; o += f;
-    l.at1 = o; o += h;
-    l.at2 = o; o += h;
-    l.ffd = o; o += 4 * h;
-    l.part = o; o += rows * (size_t)H * CROSS_SPLITS_MAX * 66 * 4;
-    l.total = (o + 255) & ~(size_t)255;
-    return l;
-}
-
-struct MegaArgs {
-    const MegaLayerW *layers;
-    int n_layer, d, H, TC, n, n_ctx, splits, per;
-    const float *x0;  // [n][d] token + position embeddings
-    char *act;        // activation arena, act_layer_stride bytes per layer
-    size_t act_layer_stride;
-    float *x_out;     // [n][d] residual stream after the last layer
-    const int *slot, *pos, *kv_idx;
-    unsigned *sync;   // barrier counters / flags / abort word (mega_sync_bytes(), zeroed once)
-    unsigned epoch_base;  // barriers completed by earlier launches on this sync area
-    float qk_scale;
-    unsigned long long *prof;  // optional [n_layer][grid][MEGA_PROF_STRIDE] wall-clock stamps (100 MHz), or null
-};
+constexpr int TILE_THREADS = 512;
+constexpr int TILE_TC_MAX = 448;         // text positions one self-attention pass covers
 // workgroup-wide attention kernels for the <= 5-row step (bf16 K/V): every load of a (row, head) or (head, split)
 // item is issued up front; the cross kernel's last split per head combines the partial softmaxes itself
 // (head_cnt: H zeroed counters, left zeroed)
@@ -212,14 +165,8 @@ void launch_self_attn_wg(const float *q, const void *kcache, const void *vcache,
 void launch_cross_attn_wg(const float *q, const void *kc, const void *vc, float *partial, void *out, DType out_t, unsigned *head_cnt,
                           int n, int H, int d, int n_ctx, int splits, hipStream_t st);
 // one decode projection on the matrix cores, workgroup = 16-feature tile (bf16 weights, <= 5 rows; direct classes
-// take bf16 rows, fc1 writes bf16 rows: the GemvArgs contract of launch_gemv_mfma)
+// take bf16 rows, fc1 writes bf16 rows)
 void launch_proj_wg(const GemvArgs &a, hipStream_t st);
-int mega_barriers_per_launch(int n_layer);
-size_t mega_sync_bytes();
-constexpr int MEGA_SYNC_ABORT_WORD = 32;
-bool mega_supported(int d, int H, int TC, int n_layer, int grid, std::string *why);
-int mega_max_grid(int device);  // workgroups that can be co-resident (0: kernel does not fit)
-void launch_decode_mega(const MegaArgs &a, int grid, hipStream_t st);
 
 // ------------------------------------------------------------------------------------------
 // K9/K10 logits rules + samplers (logits.hip)

@@ -102,35 +102,48 @@ def test_contexts_are_reentrant_across_threads(pkg, model_file):
     assert out == alone
 
 
-def test_unfused_sampler_and_lds_direct_gemm_give_the_same_results(pkg, model_file, monkeypatch):
-    # Experiment switches that select other kernels / launch structures of the SAME arithmetic:
+def test_every_environment_switch_gives_the_same_results(pkg, model_file, monkeypatch):
+    # The library reads its environment switches once, when a context is created; each selects other kernels / another
+    # launch structure of the SAME arithmetic.  One context per switch, compared with a default context:
     #  * MI355_WHISPER_NO_FUSED_SAMPLE: rules + samplers as launches of their own behind the decode graph (the form the
     #    bench's launch-by-launch roofline leg also runs) -> identical tokens, beam search included;
-    #  * MI355_WHISPER_GEMM_GLDS: encoder GEMM operands staged by global_load_lds instead of the register ring; both
-    #    accumulate the same k-steps in the same order -> bit-identical encoder output.
-    path = model_file("tiny.en", ftype=1, n_audio_layer=2, n_text_layer=2)
+    #  * MI355_WHISPER_NO_STEP_BEGIN: copy node + index-table and embedding kernels instead of the one kernel that reads the
+    #    step block from pinned host memory -> identical tokens;
+    #  * MI355_WHISPER_NO_GRAPH: the step as eager launches instead of a replayed hipGraph -> identical tokens;
+    #  * MI355_WHISPER_GEMM_GLDS=1: encoder GEMM operands staged by global_load_lds instead of the register ring; both
+    #    accumulate the same k-steps in the same order -> bit-identical encoder output;
+    #  * MI355_WHISPER_NO_FLASH_ATTN: encoder attention as QK^T, softmax, PV launches with bf16 probabilities instead of the
+    #    fused kernel -> encoder output within the bf16 tolerance of test_encoder_bf16 (relative error < 1 %).
+    path = model_file("tiny.en", ftype=1, n_audio_layer=2, n_text_layer=2, n_audio_state=512, n_audio_head=8,
+                      n_text_state=512, n_text_head=8)
     pcm = ggml_io.synth_pcm(11, 12.0)
     base_tok, base_seg = _forced_tokens(pkg, path, pcm, 24, pkg.PRECISION_BF16, strategy=1, language="en")
-    monkeypatch.setenv("MI355_WHISPER_NO_FUSED_SAMPLE", "1")
-    tok, seg = _forced_tokens(pkg, path, pcm, 24, pkg.PRECISION_BF16, strategy=1, language="en")
-    monkeypatch.delenv("MI355_WHISPER_NO_FUSED_SAMPLE")
-    assert tok == base_tok and seg == base_seg and len(tok) >= 20
-    #  * MI355_WHISPER_NO_STEP_BEGIN: copy node + index-table and embedding kernels instead of the one kernel that reads the
-    #    step block from pinned host memory -> identical tokens
-    monkeypatch.setenv("MI355_WHISPER_NO_STEP_BEGIN", "1")
-    tok, seg = _forced_tokens(pkg, path, pcm, 24, pkg.PRECISION_BF16, strategy=1, language="en")
-    monkeypatch.delenv("MI355_WHISPER_NO_STEP_BEGIN")
-    assert tok == base_tok and seg == base_seg
-    eng = pkg.Engine(path, precision=pkg.PRECISION_BF16)
-    try:
-        eng.mel(pcm)
-        ref = eng.encode(0).copy()
-        monkeypatch.setenv("MI355_WHISPER_GEMM_GLDS", "1")
-        got = eng.encode(0).copy()
-        monkeypatch.delenv("MI355_WHISPER_GEMM_GLDS")
-        assert np.isfinite(ref).all() and np.array_equal(got, ref)
-    finally:
-        eng.close()
+    assert len(base_tok) >= 20
+    for switch in ("MI355_WHISPER_NO_FUSED_SAMPLE", "MI355_WHISPER_NO_STEP_BEGIN", "MI355_WHISPER_NO_GRAPH"):
+        monkeypatch.setenv(switch, "1")
+        tok, seg = _forced_tokens(pkg, path, pcm, 24, pkg.PRECISION_BF16, strategy=1, language="en")
+        monkeypatch.delenv(switch)
+        assert tok == base_tok and seg == base_seg, switch
+
+    def encoder_out(**env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = pkg.Engine(path, precision=pkg.PRECISION_BF16)
+        for k in env:
+            monkeypatch.delenv(k)
+        try:
+            eng.mel(pcm)
+            return eng.encode(0).copy()
+        finally:
+            eng.close()
+
+    ref = encoder_out()
+    assert np.isfinite(ref).all()
+    assert np.array_equal(encoder_out(MI355_WHISPER_GEMM_GLDS="1"), ref)
+    unfused = encoder_out(MI355_WHISPER_NO_FLASH_ATTN="1")
+    rel = float(np.abs(unfused - ref).max() / np.abs(ref).max())
+    print(f"unfused vs fused encoder attention: max rel diff {rel:.4f}")
+    assert rel < 0.01
 
 
 def test_stream_contexts_share_one_weight_upload(pkg, model_file, monkeypatch):
