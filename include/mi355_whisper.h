@@ -70,7 +70,10 @@ int mw_get_cross_kv(struct whisper_context *ctx, int layer, int is_v, float *out
 /* decode n tokens of sequence `seq` at positions n_past..n_past+n-1; keeps logits of the last
    min(n, 32) tokens */
 int mw_decode(struct whisper_context *ctx, const whisper_token *tokens, int n, int n_past, int seq);
-/* out[rows][n_vocab]; rows = min(n, 32) of the last mw_decode */
+/* ONE decode step over n rows of different sequences (the shape of a beam step: n <= 32 rows, row i = token tokens[i] of
+   sequence seq[i] at position pos[i]); keeps the logits of every row.  For teacher-forced parity tests. */
+int mw_decode_rows(struct whisper_context *ctx, const whisper_token *tokens, const int *pos, const int *seq, int n);
+/* out[rows][n_vocab]; rows = min(n, 32) of the last mw_decode / mw_decode_rows */
 int mw_get_logits(struct whisper_context *ctx, float *out);
 /* forget every cached key/value (start of a new prompt) */
 int mw_kv_clear(struct whisper_context *ctx);

@@ -102,7 +102,7 @@ EXPORTED_SYMBOLS = [
     "whisper_token_transcribe", "whisper_tokenize",
     "mw_full_device", "mw_profile_begin", "mw_profile_end",
     "mw_init_from_file", "mw_init_from_buffer", "mw_init_shared", "mw_hparams", "mw_pcm_to_mel", "mw_pcm_to_mel_device", "mw_pcm_to_mel_noalloc", "mw_mel_n_len",
-    "mw_get_mel", "mw_encode", "mw_get_encoder_out", "mw_get_cross_kv", "mw_decode", "mw_get_logits", "mw_kv_clear",
+    "mw_get_mel", "mw_encode", "mw_get_encoder_out", "mw_get_cross_kv", "mw_decode", "mw_decode_rows", "mw_get_logits", "mw_kv_clear",
     "mw_process_logits", "mw_get_timings", "mw_reset_timings", "mw_stream", "mw_synchronize",
     "mw_set_force_decode_steps", "mw_set_duplicate_class", "mw_bench_decode_step", "mw_bench_mel", "mw_bench_encode", "mw_last_error",
     "lv_filter_create", "lv_filter_destroy", "lv_filter_params", "lv_filter_set_language", "lv_filter_set_thresholds",
@@ -196,6 +196,7 @@ def lib():
     L.mw_get_encoder_out.argtypes = [P, FP]
     L.mw_get_cross_kv.argtypes = [P, C.c_int, C.c_int, FP]
     L.mw_decode.argtypes = [P, IP, C.c_int, C.c_int, C.c_int]
+    L.mw_decode_rows.argtypes = [P, IP, IP, IP, C.c_int]
     L.mw_get_logits.argtypes = [P, FP]
     L.mw_kv_clear.argtypes = [P]
     L.mw_process_logits.argtypes = [P, C.POINTER(FullParams), C.c_float, FP, IP, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -354,6 +355,16 @@ class Engine:
         t = np.ascontiguousarray(tokens, dtype=np.int32)
         self._check(self.L.mw_decode(self.ctx, t.ctypes.data_as(C.POINTER(C.c_int32)), len(t), n_past, seq), "mw_decode")
         out = np.empty((min(len(t), 32), self.n_vocab), np.float32)
+        self._check(self.L.mw_get_logits(self.ctx, _fp(out)), "mw_get_logits")
+        return out
+
+    def decode_rows(self, tokens, pos, seq) -> np.ndarray:
+        """One step over len(tokens) rows of different sequences (beam-step shape); logits of every row."""
+        t, p, s = (np.ascontiguousarray(x, dtype=np.int32) for x in (tokens, pos, seq))
+        ip = C.POINTER(C.c_int32)
+        self._check(self.L.mw_decode_rows(self.ctx, t.ctypes.data_as(ip), p.ctypes.data_as(ip), s.ctypes.data_as(ip), len(t)),
+                    "mw_decode_rows")
+        out = np.empty((len(t), self.n_vocab), np.float32)
         self._check(self.L.mw_get_logits(self.ctx, _fp(out)), "mw_get_logits")
         return out
 

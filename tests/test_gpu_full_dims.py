@@ -1,0 +1,148 @@
+"""GPU: the benchmarked configurations at their OWN dimensions against the oracle, teacher-forced.
+
+  BASELINE configs[2]  Whisper large-v3 dims (d=1280, 32+32 layers, 128 mel bins, vocab 51866), bf16, 5 rows per step
+  BASELINE configs[3]  large-v3-turbo dims (4 decoder layers), bf16, 8 concurrent contexts on one upload of the weights
+
+Seeded synthetic weights in the GGML container (tools/synth_large; no checkpoints exist offline).  The bf16 engine cannot be
+token-exact against the fp32 oracle, so the comparison is teacher-forced: the ORACLE's token histories are fed to both
+sides, one step at a time (5 rows of 5 different sequences per engine step = the beam-5 shape the bench runs), and every
+step is checked on its own:
+  * encoder output: max |engine - oracle| <= ENC_TOL x max |oracle|
+  * logits of every row: max |engine - oracle| <= LOGIT_TOL x (max - min of the oracle's row)   (stated bf16 tolerance)
+  * top-1 agreement on every row whose oracle top-2 margin exceeds twice that row's tolerance
+A 12-token prompt on a sixth sequence covers the > 5-row prefill path (VALU kernels on bf16 weights) at full width.
+"""
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle
+from tools import ggml_io, synth_large
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
+
+ENC_TOL = 0.02     # bf16 operands through 32 encoder layers (measured 0.008)
+LOGIT_TOL = 0.01   # of the row's logit spread, through up to 32 decoder layers (measured 0.005)
+
+
+@pytest.fixture(scope="module")
+def big_model(tmp_path_factory):
+    d = tmp_path_factory.mktemp("full_dims")
+    cache = {}
+
+    def get(preset):
+        if preset not in cache:
+            path = str(d / f"ggml-{preset}-synth-s1234.bin")
+            synth_large.write_large(path, preset, seed=1234, quiet_special=True)
+            cache[preset] = path
+        return cache[preset]
+
+    return get
+
+
+def _teacher_forced(pkg, path, n_rows=5, steps=8):
+    pyoracle.lib().ow_set_threads(16)
+    pcm = ggml_io.synth_pcm(100, 30.0)
+    orc = pyoracle.Oracle(path)
+    eng = pkg.Engine(path, precision=pkg.PRECISION_BF16)
+    try:
+        orc.mel(pcm)
+        eng.mel(pcm)
+        eo, eg = orc.encode(0), eng.encode(0)
+        enc_rel = float(np.abs(eg - eo).max() / np.abs(eo).max())
+        print(f"encoder [{eo.shape[0]} x {eo.shape[1]}], {orc.n_audio_layer} layers: max |bf16 - fp32 oracle| / max |oracle| = {enc_rel:.4f}")
+        assert np.isfinite(eg).all() and enc_rel < ENC_TOL
+        lang_en = orc.sot + 1
+        prompt = [orc.sot, lang_en, orc.transcribe]
+        worst, checked_top1, agree_top1 = 0.0, 0, 0
+        margins = []
+
+        def compare(ref_row, got_row, what):
+            nonlocal worst, checked_top1, agree_top1
+            spread = float(ref_row.max() - ref_row.min())
+            err = float(np.abs(got_row - ref_row).max())
+            worst = max(worst, err / spread)
+            assert err <= LOGIT_TOL * spread, f"{what}: |d logits| {err:.4f} > {LOGIT_TOL} x spread {spread:.3f}"
+            top2 = np.partition(ref_row, -2)[-2:]
+            margins.append(float(top2[1] - top2[0]) / spread)
+            if float(top2[1] - top2[0]) > 2.0 * LOGIT_TOL * spread:
+                checked_top1 += 1
+                agree_top1 += int(np.argmax(got_row) == np.argmax(ref_row))
+                assert np.argmax(got_row) == np.argmax(ref_row), what
+
+        # prompt prefill per sequence (3 rows in one call), then row r continues with the oracle's (r+1)-th best text token
+        hist = []
+        for r in range(n_rows):
+            ref = orc.decode(prompt, 0, r)
+            got = eng.decode(prompt, 0, r)
+            for i in range(len(prompt)):
+                compare(ref[i], got[i], f"prefill seq {r} row {i}")
+            order = np.argsort(-ref[-1][:orc.eot])
+            hist.append([int(order[r])])
+        n_past = len(prompt)
+        for s in range(steps):
+            toks = [h[-1] for h in hist]
+            got = eng.decode_rows(toks, [n_past] * n_rows, list(range(n_rows)))   # ONE engine step, n_rows sequences
+            for r in range(n_rows):
+                ref = orc.decode([toks[r]], n_past, r)[0]
+                compare(ref, got[r], f"step {s} row {r}")
+                hist[r].append(int(np.argmax(ref[:orc.eot])))                     # teacher forcing: the ORACLE's choice
+            n_past += 1
+        # > 5 rows in one call: a 12-token prompt on another sequence (prefill path)
+        long_prompt = [orc.prev] + [int(t) for t in hist[0][:8]] + prompt
+        ref = orc.decode(long_prompt, 0, n_rows)
+        got = eng.decode(long_prompt, 0, n_rows)
+        for i in (0, 5, len(long_prompt) - 1):
+            compare(ref[i], got[i], f"12-token prefill row {i}")
+        print(f"{orc.n_text_layer} decoder layers, {n_rows} rows x {steps} teacher-forced steps: worst |d logits| / spread = {worst:.4f}; "
+              f"top-1 equal on {agree_top1}/{checked_top1} rows with a decisive oracle margin")
+        print("oracle top-2 margins / spread: median %.4f, max %.4f, %d rows" % (float(np.median(margins)), max(margins), len(margins)))
+    finally:
+        eng.close()
+        orc.close()
+
+
+def test_large_v3_dims_bf16_teacher_forced_beam5_rows(pkg, big_model):
+    _teacher_forced(pkg, big_model("large-v3"), n_rows=5, steps=8)
+
+
+def test_turbo_dims_bf16_teacher_forced_and_8_shared_weight_contexts(pkg, big_model):
+    path = big_model("large-v3-turbo")
+    _teacher_forced(pkg, path, n_rows=5, steps=8)
+    # configs[3]: concurrent streams on ONE upload of the weights give each stream the tokens it gets alone
+    n_streams, steps = 8, 24
+    clips = [ggml_io.synth_pcm(100 + i, 30.0) for i in range(n_streams)]
+    first = pkg.Engine(path, precision=pkg.PRECISION_BF16)
+    engs = [first] + [pkg.Engine(path, precision=pkg.PRECISION_BF16, share=first) for _ in range(n_streams - 1)]
+    try:
+        params = []
+        for e in engs:
+            e.set_force_decode_steps(steps)
+            params.append(e.default_params(pkg.SAMPLING_GREEDY, temperature_inc=0.0, duration_ms=30000, language="en"))
+        solo = []
+        for i, e in enumerate(engs):
+            assert e.full(params[i], clips[i]) == 0
+            solo.append(e.token_ids())
+        assert all(len(t) >= steps // 2 for t in solo)
+        assert len({tuple(t) for t in solo}) > 1          # the clips do lead to different transcripts
+        out, errs = [None] * n_streams, []
+
+        def work(i):
+            try:
+                for _ in range(2):
+                    assert engs[i].full(params[i], clips[i]) == 0
+                    out[i] = engs[i].token_ids()
+            except Exception as ex:  # noqa: BLE001
+                errs.append(repr(ex))
+
+        th = [threading.Thread(target=work, args=(i,)) for i in range(n_streams)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, errs
+        assert out == solo
+    finally:
+        for e in engs[1:] + engs[:1]:
+            e.close()
