@@ -59,3 +59,22 @@ def test_assign_streams_edges():
     import pytest
     with pytest.raises(ValueError):
         stream_shard.assign_streams(4, 2, 2)
+
+
+def test_bench_launches_its_own_ranks():
+    # `python bench.py --gpus 2` run plainly (no torch.distributed.run around it) starts the two ranks itself; --dry-run
+    # keeps the rendezvous (gloo), the barrier, the MAX-reduced time and the single JSON line, and skips the GPU work.
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--workload", "streams",
+                          "--streams", "7"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 prints ONE line
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["dry_run"] is True
+    assert rec["streams_per_rank"] == [4, 3]                 # stream i -> rank i mod 2
+    assert rec["elapsed_max_s"] >= 0.02                      # rank 1 is the slow one (MAX over ranks)
