@@ -104,7 +104,7 @@ EXPORTED_SYMBOLS = [
     "mw_init_from_file", "mw_init_from_buffer", "mw_init_shared", "mw_hparams", "mw_pcm_to_mel", "mw_pcm_to_mel_device", "mw_pcm_to_mel_noalloc", "mw_mel_n_len",
     "mw_get_mel", "mw_encode", "mw_get_encoder_out", "mw_get_cross_kv", "mw_decode", "mw_decode_rows", "mw_get_logits", "mw_kv_clear",
     "mw_process_logits", "mw_get_timings", "mw_reset_timings", "mw_stream", "mw_synchronize",
-    "mw_set_force_decode_steps", "mw_set_duplicate_class", "mw_bench_decode_step", "mw_bench_mel", "mw_bench_encode", "mw_last_error",
+    "mw_set_force_decode_steps", "mw_hub_stats", "mw_set_duplicate_class", "mw_bench_decode_step", "mw_bench_mel", "mw_bench_encode", "mw_last_error",
     "lv_filter_create", "lv_filter_destroy", "lv_filter_params", "lv_filter_set_language", "lv_filter_set_thresholds",
     "lv_filter_set_context_sentences", "lv_filter_push_sentence", "lv_filter_set_gpu_device", "lv_filter_load_model",
     "lv_filter_unload_model", "lv_filter_context", "lv_run_whisper_inference", "lv_to_timestamp",
@@ -208,6 +208,7 @@ def lib():
     L.mw_synchronize.argtypes = [P]
     L.mw_set_force_decode_steps.argtypes = [P, C.c_int]
     L.mw_set_duplicate_class.argtypes = [P, C.c_int]
+    L.mw_hub_stats.argtypes = [P, C.POINTER(C.c_ulonglong)]
     L.mw_bench_decode_step.argtypes = [P, C.c_int, C.c_int, C.c_int, FP]
     L.mw_bench_mel.argtypes = [P, C.c_int, C.c_int, FP]
     L.mw_bench_encode.argtypes = [P, C.c_int, FP]
@@ -416,6 +417,12 @@ class Engine:
 
     def set_force_decode_steps(self, n: int):
         self._check(self.L.mw_set_force_decode_steps(self.ctx, n), "mw_set_force_decode_steps")
+
+    def hub_stats(self):
+        """(steps, rows, requests) of the batcher shared with the other contexts on these weights, or None."""
+        out = (C.c_ulonglong * 3)()
+        rc = self.L.mw_hub_stats(self.ctx, out)
+        return None if rc != 0 else tuple(int(x) for x in out)
 
     def timings(self) -> Timings:
         t = Timings()

@@ -76,6 +76,7 @@ struct SharedModelEntry {
     long long size, mtime_ns;
     Model view;  // owners reset
     std::weak_ptr<void> arena, mel_tab;
+    std::weak_ptr<Hub> hub;
 };
 std::mutex g_models_mutex;
 std::vector<SharedModelEntry> g_models;
@@ -121,6 +122,7 @@ whisper_context *init_from_file(const char *path, int device, DType wt) {
                     donor->model = e.view;
                     donor->model.arena_owner = a;
                     donor->model.mel_tab_owner = t;
+                    donor->model.hub = e.hub.lock();
                 }
                 ++i;
             }
@@ -145,9 +147,11 @@ whisper_context *init_from_file(const char *path, int device, DType wt) {
     whisper_context *ctx = init_from_buffer(buf.data(), buf.size(), device, wt);
     if (ctx && have_id) {
         std::lock_guard<std::mutex> lk(g_models_mutex);
-        SharedModelEntry e{path, device, wt, fsize, fmtime, ctx->c->model, ctx->c->model.arena_owner, ctx->c->model.mel_tab_owner};
+        SharedModelEntry e{path, device, wt, fsize, fmtime, ctx->c->model, ctx->c->model.arena_owner, ctx->c->model.mel_tab_owner,
+                           ctx->c->model.hub};
         e.view.arena_owner.reset();
         e.view.mel_tab_owner.reset();
+        e.view.hub.reset();
         g_models.push_back(std::move(e));
     }
     return ctx;
@@ -638,6 +642,18 @@ int mw_synchronize(struct whisper_context *ctx) {
 int mw_set_force_decode_steps(struct whisper_context *ctx, int n) {
     if (!ctx || !ctx->c || n < 0) return -1;
     ctx->c->force_decode_steps = n;
+    return 0;
+}
+
+int mw_hub_stats(struct whisper_context *ctx, unsigned long long out[3]) {
+    if (!ctx || !ctx->c || !out) return -1;
+    out[0] = out[1] = out[2] = 0;
+    Hub *h = ctx->c->model.hub.get();
+    if (!h || !ctx->c->use_hub) return 1;  // this context runs its own steps (fp32 mode or a width without tile kernels)
+    std::lock_guard<std::mutex> lk(h->mu);
+    out[0] = h->n_steps;
+    out[1] = h->n_rows;
+    out[2] = h->n_requests;
     return 0;
 }
 

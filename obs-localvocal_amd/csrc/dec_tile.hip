@@ -95,6 +95,9 @@ struct Epi {
     // EPI_GELU_BF16
     bf16_t *hout;
     int ldo;
+    // batched step (EPI_QKV): when set, row i writes K / V through rows[i] (its context's cache + kv_layer_off elements)
+    const StepRow *rows;
+    long kv_layer_off;
 };
 
 __device__ __forceinline__ float wave_total(float v) {  // DPP reduction, result broadcast as a scalar
@@ -139,22 +142,26 @@ __device__ __forceinline__ void proj_finish(float v, int erow, int n_e, const Pr
 // 2w and 2w+1 as consecutive 1 KB pieces — and re-read from LDS in the MFMA B-fragment layout.  Loading the
 // fragments straight from global memory touches 64 cache lines per instruction (16 bytes of each) instead of
 // 8 and was 1.3-1.4 us slower per launch (tools/microbench/mb_latency, "B-fragment pattern").
-template <int NB, int EPI, int FR>
+template <int NB, int EPI, int FR, bool DESC>
 __device__ __forceinline__ void proj_ln_tile(const Proj &p, const float *xin, const float *ln_w, const float *ln_b, int n, const Epi &e,
                                              bf16_t *xs, bf16_t *wt, float *red, unsigned long long *stamp) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
     const int K = p.K, nf4 = K >> 2, ksteps = K >> 5, ldxs = K + 8, tile = blockIdx.x;
+    constexpr int RW = (NB + 7) / 8;  // rows a wave normalises: wave w takes rows w, w + 8 (batched step: up to 16 rows)
     // ---- every global load of the kernel, in the order their values are needed ----
     // (a wave without a row issues the same loads with every lane on one address: a single cache-line request each,
     // still straight-line code — a branch around the loads made the compiler wait for them inside the branch)
-    const bool has_row = wave < n;
-    const float *xr = xin + (long)(has_row ? wave : 0) * K;
-    float4 v[LN_MAX_F4], gw[LN_MAX_F4], gb[LN_MAX_F4];
+    float4 v[RW][LN_MAX_F4], gw[LN_MAX_F4], gb[LN_MAX_F4];
 #pragma unroll
-    for (int i = 0; i < LN_MAX_F4; ++i) v[i] = *reinterpret_cast<const float4 *>(xr + (has_row ? 4 * min(lane + 64 * i, nf4 - 1) : 0));
+    for (int rw = 0; rw < RW; ++rw) {
+        const bool has_row = wave + 8 * rw < n;
+        const float *xr = xin + (long)(has_row ? wave + 8 * rw : 0) * K;
+#pragma unroll
+        for (int i = 0; i < LN_MAX_F4; ++i) v[rw][i] = *reinterpret_cast<const float4 *>(xr + (has_row ? 4 * min(lane + 64 * i, nf4 - 1) : 0));
+    }
 #pragma unroll
     for (int i = 0; i < LN_MAX_F4; ++i) {
-        const int c = has_row ? 4 * min(lane + 64 * i, nf4 - 1) : 0;
+        const int c = wave < n ? 4 * min(lane + 64 * i, nf4 - 1) : 0;
         gw[i] = *reinterpret_cast<const float4 *>(ln_w + c);
         gb[i] = *reinterpret_cast<const float4 *>(ln_b + c);
     }
@@ -171,31 +178,44 @@ __device__ __forceinline__ void proj_ln_tile(const Proj &p, const float *xin, co
     const int n_e = tile * FR + min(16 * et + (el & 15), FR - 1);
     const float bias_e = p.bias ? p.bias[n_e] : 0.0f;
     long kv_off = 0;
+    bf16_t *kc_e = e.kc, *vc_e = e.vc;
     if constexpr (EPI == EPI_QKV) {
         const int rr = erow < n ? erow : 0;
-        kv_off = ((long)e.slot[rr] * e.TC + e.pos[rr]) * e.d;
+        if constexpr (DESC) {  // batched step: the row's own context (compile-time choice: a run-time branch around these
+                               // loads would end in a wait for every load issued before it, the weights included)
+            const StepRow *R = e.rows + rr;
+            kv_off = ((long)R->slot * e.TC + R->pos) * e.d + e.kv_layer_off;
+            kc_e = R->kself;
+            vc_e = R->vself;
+        } else {
+            kv_off = ((long)e.slot[rr] * e.TC + e.pos[rr]) * e.d;
+        }
     }
-    // ---- LayerNorm of the wave's row (wave reductions only) -> bf16 in LDS ----
-    float s = 0.0f;
+    // ---- LayerNorm of the wave's row(s) (wave reductions only) -> bf16 in LDS ----
 #pragma unroll
-    for (int i = 0; i < LN_MAX_F4; ++i) s += lane + 64 * i < nf4 ? (v[i].x + v[i].y) + (v[i].z + v[i].w) : 0.0f;
-    const float mean = wave_total(s) * (1.0f / (float)K);
-    float q = 0.0f;
+    for (int rw = 0; rw < RW; ++rw) {
+        const int row = wave + 8 * rw;
+        float s = 0.0f;
 #pragma unroll
-    for (int i = 0; i < LN_MAX_F4; ++i) {
-        const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
-        q += lane + 64 * i < nf4 ? (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3) : 0.0f;
-    }
-    const float rstd = rsqrtf(wave_total(q) * (1.0f / (float)K) + 1e-5f);
+        for (int i = 0; i < LN_MAX_F4; ++i) s += lane + 64 * i < nf4 ? (v[rw][i].x + v[rw][i].y) + (v[rw][i].z + v[rw][i].w) : 0.0f;
+        const float mean = wave_total(s) * (1.0f / (float)K);
+        float q = 0.0f;
 #pragma unroll
-    for (int i = 0; i < LN_MAX_F4; ++i) {
-        const int c = lane + 64 * i;
-        const float y0 = (v[i].x - mean) * rstd * gw[i].x + gb[i].x, y1 = (v[i].y - mean) * rstd * gw[i].y + gb[i].y;
-        const float y2 = (v[i].z - mean) * rstd * gw[i].z + gb[i].z, y3 = (v[i].w - mean) * rstd * gw[i].w + gb[i].w;
-        uint2 pk;
-        pk.x = (unsigned)to_bf16(y0) | ((unsigned)to_bf16(y1) << 16);
-        pk.y = (unsigned)to_bf16(y2) | ((unsigned)to_bf16(y3) << 16);
-        if (c < nf4 && wave < n) *reinterpret_cast<uint2 *>(xs + wave * ldxs + 4 * c) = pk;
+        for (int i = 0; i < LN_MAX_F4; ++i) {
+            const float a0 = v[rw][i].x - mean, a1 = v[rw][i].y - mean, a2 = v[rw][i].z - mean, a3 = v[rw][i].w - mean;
+            q += lane + 64 * i < nf4 ? (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3) : 0.0f;
+        }
+        const float rstd = rsqrtf(wave_total(q) * (1.0f / (float)K) + 1e-5f);
+#pragma unroll
+        for (int i = 0; i < LN_MAX_F4; ++i) {
+            const int c = lane + 64 * i;
+            const float y0 = (v[rw][i].x - mean) * rstd * gw[i].x + gb[i].x, y1 = (v[rw][i].y - mean) * rstd * gw[i].y + gb[i].y;
+            const float y2 = (v[rw][i].z - mean) * rstd * gw[i].z + gb[i].z, y3 = (v[rw][i].w - mean) * rstd * gw[i].w + gb[i].w;
+            uint2 pk;
+            pk.x = (unsigned)to_bf16(y0) | ((unsigned)to_bf16(y1) << 16);
+            pk.y = (unsigned)to_bf16(y2) | ((unsigned)to_bf16(y3) << 16);
+            if (c < nf4 && row < n) *reinterpret_cast<uint2 *>(xs + row * ldxs + 4 * c) = pk;
+        }
     }
     if (stamp && tid == 0) stamp[0] = wall_clock64();
     // ---- the wave's two weight rows -> LDS ----
@@ -240,8 +260,8 @@ __device__ __forceinline__ void proj_ln_tile(const Proj &p, const float *xin, co
         if constexpr (EPI == EPI_QKV) {
             const int d = e.d;
             if (n_e < d) st_agent(e.q + (long)erow * d + n_e, r * e.qk_scale);
-            else if (n_e < 2 * d) st_agent(e.kc + kv_off + (n_e - d), to_bf16(r * e.qk_scale));
-            else st_agent(e.vc + kv_off + (n_e - 2 * d), to_bf16(r));
+            else if (n_e < 2 * d) st_agent(kc_e + kv_off + (n_e - d), to_bf16(r * e.qk_scale));
+            else st_agent(vc_e + kv_off + (n_e - 2 * d), to_bf16(r));
         } else {
             proj_finish<EPI>(r, erow, n_e, p, e, 0.0f);
         }
@@ -259,19 +279,25 @@ template <int NB, int SPC, int CH, int FR>
 __device__ __forceinline__ void proj_res_tile(const Proj &p, const bf16_t *xin, int n, const Epi &e, bf16_t *lds_t, float *red,
                                               unsigned long long *stamp) {
     constexpr int KC = 32 * SPC, LDT = KC + 8, PPR = 4 * SPC;  // k per chunk, LDS row stride, 16-byte pieces per row segment
-    constexpr int XLD = CH * KC + 8, XPR = PPR * CH;           // the wave's x tile: row stride, pieces per row
-    constexpr int XI = (NB * XPR + 63) / 64;                   // x load instructions
-    constexpr int WI = (FR * PPR + 63) / 64;                   // weight load instructions per chunk (FR feature rows per workgroup)
+    // the wave's x tile: its whole k-range at once for the beam step (<= 8 rows), chunk by chunk for the batched step
+    // (16 rows x the whole range of fc2 would not fit the LDS)
+    constexpr bool XCH = NB > 8;
+    constexpr int XST = XCH ? CH : 1;                            // x stages
+    constexpr int XLD = (XCH ? KC : CH * KC) + 8, XPR = XCH ? PPR : PPR * CH;  // row stride, pieces per row of a stage
+    constexpr int XI = (NB * XPR + 63) / 64;                     // x load instructions per stage
+    constexpr int WI = (FR * PPR + 63) / 64;                     // weight load instructions per chunk (FR feature rows per workgroup)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
     const int K = p.K, tile = blockIdx.x, kw = wave * CH * KC;
-    u32x4v xv[XI];  // first-class vectors: as HIP uint4 structs this array was not split into registers and went through
-                    // LDS scratch, whose indexing reads the workgroup size from the dispatch packet in host memory (2-6 us)
+    u32x4v xv[XST][XI];  // first-class vectors: as HIP uint4 structs this array was not split into registers and went through
+                         // LDS scratch, whose indexing reads the workgroup size from the dispatch packet in host memory (2-6 us)
     uint4 w[CH][WI];
 #pragma unroll
-    for (int i = 0; i < XI; ++i) {
-        const int pc = min(lane + 64 * i, NB * XPR - 1);
-        xv[i] = *reinterpret_cast<const u32x4v *>(xin + (long)min(pc / XPR, n - 1) * K + kw + 8 * (pc % XPR));
-    }
+    for (int s2 = 0; s2 < XST; ++s2)
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const int pc = min(lane + 64 * i, NB * XPR - 1);
+            xv[s2][i] = *reinterpret_cast<const u32x4v *>(xin + (long)min(pc / XPR, n - 1) * K + kw + s2 * KC + 8 * (pc % XPR));
+        }
     const int el = (tid & 255) >> 2, er = tid & 3, erow = 4 * (el >> 4) + er, n_e = tile * FR + min(el & 15, FR - 1);
     const float res_e = e.res[(long)(erow < n ? erow : 0) * p.N + n_e];
     const float bias_v = (p.bias ? p.bias : e.res)[n_e];  // unconditional load: a branch here would split the load block
@@ -285,15 +311,24 @@ __device__ __forceinline__ void proj_res_tile(const Proj &p, const bf16_t *xin, 
         }
     __builtin_amdgcn_sched_barrier(0);  // every load above is issued before anything below (no sinking next to the use)
     bf16_t *wt = lds_t + wave * (16 * LDT + NB * XLD), *xt = wt + 16 * LDT;
+    if constexpr (!XCH) {
 #pragma unroll
-    for (int i = 0; i < XI; ++i) {
-        const int pc = min(lane + 64 * i, NB * XPR - 1);  // surplus lanes rewrite the last piece (same data): no predicate
-        *reinterpret_cast<u32x4v *>(xt + (pc / XPR) * XLD + 8 * (pc % XPR)) = xv[i];
+        for (int i = 0; i < XI; ++i) {
+            const int pc = min(lane + 64 * i, NB * XPR - 1);  // surplus lanes rewrite the last piece (same data): no predicate
+            *reinterpret_cast<u32x4v *>(xt + (pc / XPR) * XLD + 8 * (pc % XPR)) = xv[0][i];
+        }
     }
     f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
     if (stamp && tid == 0) stamp[0] = wall_clock64();
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
+        if constexpr (XCH) {  // this chunk's x rows (the wave's LDS operations execute in order: no barrier)
+#pragma unroll
+            for (int i = 0; i < XI; ++i) {
+                const int pc = min(lane + 64 * i, NB * XPR - 1);
+                *reinterpret_cast<u32x4v *>(xt + (pc / XPR) * XLD + 8 * (pc % XPR)) = xv[c][i];
+            }
+        }
 #pragma unroll
         for (int j = 0; j < WI; ++j) {
             const int pc = min(lane + 64 * j, FR * PPR - 1);  // surplus lanes rewrite the last piece
@@ -301,7 +336,7 @@ __device__ __forceinline__ void proj_res_tile(const Proj &p, const bf16_t *xin, 
         }
 #pragma unroll
         for (int s2 = 0; s2 < SPC; ++s2) {
-            const uint4 af = *reinterpret_cast<const uint4 *>(xt + (fr < n ? fr : 0) * XLD + c * KC + 32 * s2 + 8 * fq);
+            const uint4 af = *reinterpret_cast<const uint4 *>(xt + (fr < n ? fr : 0) * XLD + (XCH ? 0 : c * KC) + 32 * s2 + 8 * fq);
             const uint4 bfr = *reinterpret_cast<const uint4 *>(wt + fr * LDT + 32 * s2 + 8 * fq);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8b, af), __builtin_bit_cast(bf16x8b, bfr), acc, 0, 0, 0);
         }
@@ -338,15 +373,19 @@ __device__ __forceinline__ void logits_tile(const bf16_t *W, const float *xin, c
     constexpr int K = NCH * LKC, nf4 = K / 4, ldxs = K + 8;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
     const int f0 = (blockIdx.x * 8 + wave) * 16;  // first vocabulary row of the wave's tile
-    // ---- loads: the wave's LayerNorm row (or one address), then the first LRING weight chunks ----
-    const bool has_row = wave < n;
-    const float *xr = xin + (long)d_rows[has_row ? wave : 0] * K;
-    float4 v[LN_MAX_F4], gw[LN_MAX_F4], gb[LN_MAX_F4];
+    // ---- loads: the wave's LayerNorm row(s) (or one address), then the first LRING weight chunks ----
+    constexpr int RW = (NB + 7) / 8;  // wave w normalises rows w, w + 8
+    float4 v[RW][LN_MAX_F4], gw[LN_MAX_F4], gb[LN_MAX_F4];
 #pragma unroll
-    for (int i = 0; i < LN_MAX_F4; ++i) v[i] = *reinterpret_cast<const float4 *>(xr + (has_row ? 4 * min(lane + 64 * i, nf4 - 1) : 0));
+    for (int rw = 0; rw < RW; ++rw) {
+        const bool has_row = wave + 8 * rw < n;
+        const float *xr = xin + (long)d_rows[has_row ? wave + 8 * rw : 0] * K;
+#pragma unroll
+        for (int i = 0; i < LN_MAX_F4; ++i) v[rw][i] = *reinterpret_cast<const float4 *>(xr + (has_row ? 4 * min(lane + 64 * i, nf4 - 1) : 0));
+    }
 #pragma unroll
     for (int i = 0; i < LN_MAX_F4; ++i) {
-        const int c = has_row ? 4 * min(lane + 64 * i, nf4 - 1) : 0;
+        const int c = wave < n ? 4 * min(lane + 64 * i, nf4 - 1) : 0;
         gw[i] = *reinterpret_cast<const float4 *>(ln_w + c);
         gb[i] = *reinterpret_cast<const float4 *>(ln_b + c);
     }
@@ -363,28 +402,30 @@ __device__ __forceinline__ void logits_tile(const bf16_t *W, const float *xin, c
 #pragma unroll
         for (int j = 0; j < 4; ++j) w[c][j] = ld_stream16(wl[j] + c * LKC);
     __builtin_amdgcn_sched_barrier(0);
-    // ---- LayerNorm of the wave's row -> bf16 in LDS ----
-    {
+    // ---- LayerNorm of the wave's row(s) -> bf16 in LDS ----
+#pragma unroll
+    for (int rw = 0; rw < RW; ++rw) {
+        const int row = wave + 8 * rw;
         float s = 0.0f;
 #pragma unroll
-        for (int i = 0; i < LN_MAX_F4; ++i) s += lane + 64 * i < nf4 ? (v[i].x + v[i].y) + (v[i].z + v[i].w) : 0.0f;
+        for (int i = 0; i < LN_MAX_F4; ++i) s += lane + 64 * i < nf4 ? (v[rw][i].x + v[rw][i].y) + (v[rw][i].z + v[rw][i].w) : 0.0f;
         const float mean = wave_total(s) * (1.0f / (float)K);
         float q = 0.0f;
 #pragma unroll
         for (int i = 0; i < LN_MAX_F4; ++i) {
-            const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
+            const float a0 = v[rw][i].x - mean, a1 = v[rw][i].y - mean, a2 = v[rw][i].z - mean, a3 = v[rw][i].w - mean;
             q += lane + 64 * i < nf4 ? (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3) : 0.0f;
         }
         const float rstd = rsqrtf(wave_total(q) * (1.0f / (float)K) + 1e-5f);
 #pragma unroll
         for (int i = 0; i < LN_MAX_F4; ++i) {
             const int c = lane + 64 * i;
-            const float y0 = (v[i].x - mean) * rstd * gw[i].x + gb[i].x, y1 = (v[i].y - mean) * rstd * gw[i].y + gb[i].y;
-            const float y2 = (v[i].z - mean) * rstd * gw[i].z + gb[i].z, y3 = (v[i].w - mean) * rstd * gw[i].w + gb[i].w;
+            const float y0 = (v[rw][i].x - mean) * rstd * gw[i].x + gb[i].x, y1 = (v[rw][i].y - mean) * rstd * gw[i].y + gb[i].y;
+            const float y2 = (v[rw][i].z - mean) * rstd * gw[i].z + gb[i].z, y3 = (v[rw][i].w - mean) * rstd * gw[i].w + gb[i].w;
             uint2 pk;
             pk.x = (unsigned)to_bf16(y0) | ((unsigned)to_bf16(y1) << 16);
             pk.y = (unsigned)to_bf16(y2) | ((unsigned)to_bf16(y3) << 16);
-            if (c < nf4 && wave < n) *reinterpret_cast<uint2 *>(xs + wave * ldxs + 4 * c) = pk;
+            if (c < nf4 && row < n) *reinterpret_cast<uint2 *>(xs + row * ldxs + 4 * c) = pk;
         }
     }
     lds_sync();
@@ -425,14 +466,28 @@ __device__ __forceinline__ void logits_tile(const bf16_t *W, const float *xin, c
 // Loads beyond the row's length are clamped to its last position (one line for the whole wave) and masked in the
 // arithmetic; nothing is predicated, so the compiler keeps each level's loads in one batch.  Probabilities stay
 // in registers (the thread that scored a key also weights its V chunk).
-template <typename OT>
+// Batched step: `rows` set -> the row's cache, index table, slot and position come from its descriptor (one more scalar
+// load level than the single-context form; the rows of a step may belong to different contexts).
+template <typename OT, bool DESC>
 __device__ __forceinline__ void self_attn_lean(const float *q, const bf16_t *kc, const bf16_t *vc, const int *slot, const int *pos,
-                                               const int *kv_idx, OT *out, int H, int d, int TC, float *red, float *sm) {
+                                               const int *kv_idx, const StepRow *rows, long kv_layer_off, OT *out, int H, int d, int TC,
+                                               float *red, float *sm) {
     constexpr int PVI = TILE_TC_MAX / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, jj = tid >> 3, e8 = tid & 7;
     const int r = blockIdx.x / H, h = blockIdx.x - r * H;
-    const int np = pos[r] + 1;
-    const int *idx = kv_idx + (long)slot[r] * TC;
+    int np, sl;
+    if constexpr (DESC) {
+        const StepRow *R = rows + r;
+        np = R->pos + 1;
+        sl = R->slot;
+        kc = R->kself + kv_layer_off;
+        vc = R->vself + kv_layer_off;
+        kv_idx = R->kv_idx;
+    } else {
+        np = pos[r] + 1;
+        sl = slot[r];
+    }
+    const int *idx = kv_idx + (long)sl * TC;
     const float4 qa = *reinterpret_cast<const float4 *>(q + (long)r * d + h * 64 + e8 * 8);
     const float4 qb = *reinterpret_cast<const float4 *>(q + (long)r * d + h * 64 + e8 * 8 + 4);
     int iv[PVI];
@@ -505,25 +560,29 @@ __device__ __forceinline__ void self_attn_lean(const float *q, const bf16_t *kc,
 constexpr int CPART = 66;
 
 // tail of a cross-attention work item: count this split of head h; the last one to arrive combines the partial
-// softmax records of all splits (fixed split order) into the output rows
+// softmax records of all splits (fixed split order) into the output rows.  Rows row0 .. row0 + n - 1 of the step
+// (row0 = 0, cnt = h for a single context; the request's rows and counter in a batched step).
 template <int NB, typename OT>
-__device__ __forceinline__ void cross_count_and_combine(const float *part, OT *out, unsigned *head_cnt, float *sc, unsigned *flag,
-                                                        int n, int H, int d, int h, int splits) {
+__device__ __forceinline__ void cross_count_and_combine(const float *part, OT *out, unsigned *head_cnt, unsigned *flag, int row0, int n,
+                                                        int H, int d, int h, int cnt, int splits) {
     const int tid = threadIdx.x;
-        __syncthreads();  // partial stores acknowledged (vmcnt(0)) before this split is counted
-        if (tid == 0) {
-            const unsigned old = __hip_atomic_fetch_add(&head_cnt[h], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned last = old == (unsigned)splits - 1;
-            if (last) __hip_atomic_store(&head_cnt[h], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
-            *flag = last;
-        }
-        lds_sync();
-        if (*flag) {  // every split of head h is in memory: combine in fixed split order
-            // one batch of unconditional loads per thread (row r, dim e): the splits' (max, sum) pairs — the same
-            // address for the 64 threads of a row — and the thread's own partial outputs; surplus slots repeat the
-            // last split and get weight zero
-            const int i = min(tid, NB * 64 - 1), r = min(i >> 6, n - 1), e = i & 63;
-            const float *pp = part + ((long)r * H + h) * splits * CPART;
+    __syncthreads();  // partial stores acknowledged (vmcnt(0)) before this split is counted
+    if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(&head_cnt[cnt], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned last = old == (unsigned)splits - 1;
+        if (last) __hip_atomic_store(&head_cnt[cnt], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+        *flag = last;
+    }
+    lds_sync();
+    if (*flag) {  // every split of head h is in memory: combine in fixed split order
+        // one batch of unconditional loads per thread (row r, dim e): the splits' (max, sum) pairs — the same
+        // address for the 64 threads of a row — and the thread's own partial outputs; surplus slots repeat the
+        // last split and get weight zero
+#pragma unroll
+        for (int it = 0; it < (NB * 64 + MT - 1) / MT; ++it) {
+            const int i0 = tid + MT * it;
+            const int i = min(i0, NB * 64 - 1), r = min(i >> 6, n - 1), e = i & 63;
+            const float *pp = part + ((long)(row0 + r) * H + h) * splits * CPART;
             float2 mlv[CROSS_SPLITS_MAX];
             float ov[CROSS_SPLITS_MAX];
 #pragma unroll
@@ -543,45 +602,59 @@ __device__ __forceinline__ void cross_count_and_combine(const float *part, OT *o
                 Lsum += w * mlv[sidx].y;
                 acc += w * ov[sidx];
             }
-            if (tid < NB * 64 && (tid >> 6) < n) st_out(out + (long)r * d + h * 64 + e, acc / Lsum);
+            if (i0 < NB * 64 && (i0 >> 6) < n) st_out(out + (long)(row0 + r) * d + h * 64 + e, acc / Lsum);
         }
+    }
 }
 
-
-// ---- cross-attention on the matrix cores (splits of at most 128 keys) ----
-// scores  S[row][key] = q[row] . K[key]:  A = q rows as bf16 (LDS), B = K rows straight from global memory (a lane's
-//         16 bytes are 8 consecutive head dims of its key), one 16-key tile per wave, 2 x v_mfma_f32_16x16x32_bf16;
+// ---- cross-attention on the matrix cores as a straight-line kernel (one (head, split) of one context per workgroup) ----
+// scores  S[row][key] = q[row] . K[key]:  A = q rows as bf16 (LDS), B = K rows, one 16-key tile per wave, 2 MFMA steps;
 // P . V   O[row][dim] = sum_key P[row][key] V[key][dim]:  B needs 8 consecutive KEYS of one dim per lane, so the V
 //         tile is transposed on its way into LDS; wave w takes dims 16*(w&3).. and key half w>>2, 2 MFMAs each.
+// Every global load is unconditional (keys beyond the split are clamped to its last key and masked in the scores) and
+// issued before anything else; K and V are loaded 8 lanes per 128-byte head row (whole cache lines per instruction)
+// and re-read from LDS in the B-fragment layout; no LDS zero-fill (operand rows beyond the real rows only feed
+// result rows nobody reads).  Batched step: `groups` set -> blockIdx.x also selects the request, whose rows
+// row0 .. row0 + nrows - 1 attend to ITS context's K / V.
 constexpr int XK = 128;      // keys per split
 constexpr int XLDP = XK + 8; // LDS row stride (elements) of the [*][key] tiles: conflict-free 16-byte reads
-
-
-// ---- cross-attention on the matrix cores as a straight-line kernel of its own (one (head, split) per workgroup) ----
-// Same arithmetic as cross_attn_phase_mfma; differences: every global load is unconditional (keys beyond the split
-// are clamped to its last key and masked in the scores) and issued before anything else; K is loaded like V, 8 lanes
-// per 128-byte head row (whole cache lines per instruction), and re-read from LDS in the B-fragment layout; no LDS
-// zero-fill (operand rows beyond the real rows only feed result rows nobody reads).
 constexpr int XKD = 64 + 8;  // LDS row stride of the [key][dim] K tile
 
-template <int NB, typename OT>
-__device__ __forceinline__ void cross_attn_lean(const float *q, const bf16_t *kc, const bf16_t *vc, float *part, OT *out,
-                                                unsigned *head_cnt, int n, int H, int d, int n_ctx, int splits, int per, float *lds) {
+template <int NB, typename OT, bool DESC>
+__device__ __forceinline__ void cross_attn_lean(const float *q, const bf16_t *kc, const bf16_t *vc, const StepGroup *groups, long k_off,
+                                                long v_off, float *part, OT *out, unsigned *head_cnt, int n, int H, int d, int n_ctx,
+                                                int splits, float *lds) {
     bf16_t *qb = reinterpret_cast<bf16_t *>(lds);  // [16][72]    q rows
     bf16_t *kt = qb + 16 * 72;                     // [XK][XKD]   K rows
     bf16_t *vt = kt + XK * XKD;                    // [64][XLDP]  V transposed: [dim][key]
     bf16_t *pb = vt + 64 * XLDP;                   // [16][XLDP]  probabilities
-    float *sc = reinterpret_cast<float *>(pb + 16 * XLDP);  // [NB][XK] scores; reused by the combine
-    float *red = sc + (NB * XK > 2 * NB * CROSS_SPLITS_MAX ? NB * XK : 2 * NB * CROSS_SPLITS_MAX);  // [8][64][4]
+    float *sc = reinterpret_cast<float *>(pb + 16 * XLDP);  // [NB][XK] scores
+    float *red = sc + NB * XK;                     // [8][64][4]
     float *ml = red + 8 * 64 * 4;                  // [NB][2]
     unsigned *flag = reinterpret_cast<unsigned *>(ml + NB * 2);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
-    const int h = blockIdx.x / splits, sp = blockIdx.x - h * splits;
+    const int hs = H * splits, g = blockIdx.x / hs, rem = blockIdx.x - g * hs;
+    const int h = rem / splits, sp = rem - h * splits;
+    int row0 = 0;
+    if constexpr (DESC) {
+        const StepGroup *G = groups + g;
+        row0 = G->row0;
+        n = G->nrows;
+        n_ctx = G->n_ctx;
+        kc = G->cross + k_off;
+        vc = G->cross + v_off;
+    }
+    const int per = (n_ctx + splits - 1) / splits;
     const int j0 = sp * per, nk = min(per, n_ctx - j0);  // may be <= 0 for a trailing split
     const int last = max(nk - 1, 0) + min(j0, n_ctx - 1);  // a valid key for clamped loads
     // ---- loads ----
-    const int qi = min(tid, NB * 64 - 1);
-    const float qv = q[(long)min(qi >> 6, n - 1) * d + h * 64 + (qi & 63)];
+    constexpr int QI = (NB * 64 + MT - 1) / MT;
+    float qv[QI];
+#pragma unroll
+    for (int it = 0; it < QI; ++it) {
+        const int qi = min(tid + MT * it, NB * 64 - 1);
+        qv[it] = q[(long)(row0 + min(qi >> 6, n - 1)) * d + h * 64 + (qi & 63)];
+    }
     const int kk = tid >> 3, e8 = tid & 7;
     u32x4v kq[2], vq[2];  // first-class vectors: component access stays in registers
 #pragma unroll
@@ -593,7 +666,11 @@ __device__ __forceinline__ void cross_attn_lean(const float *q, const bf16_t *kc
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- stage q, K and V^T ----
-    qb[(qi >> 6) * 72 + (qi & 63)] = to_bf16(qv);
+#pragma unroll
+    for (int it = 0; it < QI; ++it) {
+        const int qi = min(tid + MT * it, NB * 64 - 1);
+        qb[(qi >> 6) * 72 + (qi & 63)] = to_bf16(qv[it]);
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int key = kk + 64 * i;
@@ -622,18 +699,21 @@ __device__ __forceinline__ void cross_attn_lean(const float *q, const bf16_t *kc
         }
     }
     lds_sync();
-    // ---- per-row softmax over the split (wave w: row w) ----
-    if (wave < NB) {
-        const int r = wave;
-        const float v0 = sc[r * XK + lane], v1 = sc[r * XK + 64 + lane];
-        const float mx = wave_max_all(fmaxf(v0, v1));
-        const float e0 = lane < nk ? expf(v0 - mx) : 0.0f, e1 = (64 + lane) < nk ? expf(v1 - mx) : 0.0f;
-        const float sum = wave_sum_all(e0 + e1);
-        pb[r * XLDP + lane] = to_bf16(e0);
-        pb[r * XLDP + 64 + lane] = to_bf16(e1);
-        if (lane == 0) {
-            ml[r * 2] = mx;
-            ml[r * 2 + 1] = sum;
+    // ---- per-row softmax over the split (wave w: rows w, w + 8) ----
+#pragma unroll
+    for (int rw = 0; rw < (NB + 7) / 8; ++rw) {
+        const int r = wave + 8 * rw;
+        if (r < NB) {
+            const float v0 = sc[r * XK + lane], v1 = sc[r * XK + 64 + lane];
+            const float mx = wave_max_all(fmaxf(v0, v1));
+            const float e0 = lane < nk ? expf(v0 - mx) : 0.0f, e1 = (64 + lane) < nk ? expf(v1 - mx) : 0.0f;
+            const float sum = wave_sum_all(e0 + e1);
+            pb[r * XLDP + lane] = to_bf16(e0);
+            pb[r * XLDP + 64 + lane] = to_bf16(e1);
+            if (lane == 0) {
+                ml[r * 2] = mx;
+                ml[r * 2 + 1] = sum;
+            }
         }
     }
     lds_sync();
@@ -651,12 +731,13 @@ __device__ __forceinline__ void cross_attn_lean(const float *q, const bf16_t *kc
         *reinterpret_cast<f32x4 *>(red + (wave * 64 + lane) * 4) = acc;
     }
     lds_sync();
-    if (tid < NB * 64) {
-        const int r = tid >> 6, e = tid & 63;
-        if (r < n) {
+#pragma unroll
+    for (int it = 0; it < QI; ++it) {
+        const int i = tid + MT * it, r = i >> 6, e = i & 63;
+        if (i < NB * 64 && r < n) {
             const int nt = e >> 4, src_lane = (r >> 2) * 16 + (e & 15), rr = r & 3;
             const float v = red[(nt * 64 + src_lane) * 4 + rr] + red[((4 + nt) * 64 + src_lane) * 4 + rr];
-            float *pp = part + (((long)r * H + h) * splits + sp) * CPART;
+            float *pp = part + (((long)(row0 + r) * H + h) * splits + sp) * CPART;
             st_agent(pp + 2 + e, v);
             if (e == 0) {
                 st_agent(pp, ml[r * 2]);
@@ -664,10 +745,8 @@ __device__ __forceinline__ void cross_attn_lean(const float *q, const bf16_t *kc
             }
         }
     }
-    cross_count_and_combine<NB, OT>(part, out, head_cnt, sc, flag, n, H, d, h, splits);
+    cross_count_and_combine<NB, OT>(part, out, head_cnt, flag, row0, n, H, d, h, g * H + h, splits);
 }
-
-
 
 template <int NB, int NCH>
 __global__ __launch_bounds__(MT) void logits_tile_kernel(const bf16_t *W, const float *xin, const int *d_rows, const float *ln_w,
@@ -677,85 +756,116 @@ __global__ __launch_bounds__(MT) void logits_tile_kernel(const bf16_t *W, const 
     logits_tile<NB, NCH>(W, xin, d_rows, ln_w, ln_b, out, ldo, n, N, xs, wtile);
 }
 
-template <typename OT>
+template <typename OT, bool DESC>
 __global__ __launch_bounds__(MT) void self_attn_lean_kernel(const float *q, const bf16_t *kc, const bf16_t *vc, const int *slot,
-                                                                       const int *pos, const int *kv_idx, OT *out, int H, int d, int TC) {
+                                                                       const int *pos, const int *kv_idx, const StepRow *rows,
+                                                                       long kv_layer_off, OT *out, int H, int d, int TC) {
     __shared__ __attribute__((aligned(16))) float red[8 * 64];
     __shared__ float sm[16];
-    self_attn_lean<OT>(q, kc, vc, slot, pos, kv_idx, out, H, d, TC, red, sm);
+    self_attn_lean<OT, DESC>(q, kc, vc, slot, pos, kv_idx, rows, kv_layer_off, out, H, d, TC, red, sm);
 }
 
 
-template <int NB, int EPI, int FR>
+template <int NB, int EPI, int FR, bool DESC>
 __global__ __launch_bounds__(MT) void proj_ln_tile_kernel(Proj p, const float *xin, const float *ln_w, const float *ln_b, int n,
                                                                      Epi e) {
     __shared__ __attribute__((aligned(16))) bf16_t xs[NB * (256 * LN_MAX_F4 + 8)];
     __shared__ __attribute__((aligned(16))) bf16_t wt[FR * (256 * LN_MAX_F4 + 8)];
     __shared__ __attribute__((aligned(16))) float red[(FR > 16 ? FR / 16 : 1) * 8 * 64 * 4];
-    proj_ln_tile<NB, EPI, FR>(p, xin, ln_w, ln_b, n, e, xs, wt, red, nullptr);
+    proj_ln_tile<NB, EPI, FR, DESC>(p, xin, ln_w, ln_b, n, e, xs, wt, red, nullptr);
 }
 
 template <int NB, int SPC, int CH, int FR>
 __global__ __launch_bounds__(MT) void proj_res_tile_kernel(Proj p, const bf16_t *xin, int n, Epi e) {
-    __shared__ __attribute__((aligned(16))) bf16_t lds_t[8 * (16 * (32 * SPC + 8) + NB * (CH * 32 * SPC + 8))];
+    __shared__ __attribute__((aligned(16))) bf16_t lds_t[8 * (16 * (32 * SPC + 8) + NB * ((NB > 8 ? 1 : CH) * 32 * SPC + 8))];
     __shared__ __attribute__((aligned(16))) float red[8 * 64 * 4];
     proj_res_tile<NB, SPC, CH, FR>(p, xin, n, e, lds_t, red, nullptr);
 }
 
-template <int NB, typename OT>
-__global__ __launch_bounds__(MT) void cross_attn_lean_kernel(const float *q, const bf16_t *kc, const bf16_t *vc, float *part,
-                                                                        OT *out, unsigned *head_cnt, int n, int H, int d, int n_ctx,
-                                                                        int splits, int per) {
-    __shared__ __attribute__((aligned(16))) float lds[(16 * 72 + XK * XKD + 64 * XLDP + 16 * XLDP) / 2 + NB * XK +
-                                                      2 * NB * CROSS_SPLITS_MAX + 8 * 64 * 4 + NB * 2 + 16];
-    cross_attn_lean<NB, OT>(q, kc, vc, part, out, head_cnt, n, H, d, n_ctx, splits, per, lds);
+template <int NB, typename OT, bool DESC>
+__global__ __launch_bounds__(MT) void cross_attn_lean_kernel(const float *q, const bf16_t *kc, const bf16_t *vc, const StepGroup *groups,
+                                                              long k_off, long v_off, float *part, OT *out, unsigned *head_cnt, int n, int H,
+                                                              int d, int n_ctx, int splits) {
+    __shared__ __attribute__((aligned(16))) float lds[(16 * 72 + XK * XKD + 64 * XLDP + 16 * XLDP) / 2 + NB * XK + 8 * 64 * 4 + NB * 2 + 16];
+    cross_attn_lean<NB, OT, DESC>(q, kc, vc, groups, k_off, v_off, part, out, head_cnt, n, H, d, n_ctx, splits, lds);
 }
 
+// ---- head of a batched step: the StepBlock straight from pinned host memory ----
+// Blocks [0, n_groups * KV_SLOTS): the requests' deferred beam reshuffles of their index tables; the next n_rows blocks
+// embed one token each; the last block copies the StepBlock into device memory for the kernels behind.
+__global__ __launch_bounds__(256) void step_begin_batch_kernel(const StepBlock *__restrict__ hblk, StepBlock *__restrict__ dblk, int n_rows,
+                                                               int n_groups, int n_text_ctx, const bf16_t *__restrict__ te,
+                                                               const float *__restrict__ pe, float *__restrict__ x, int d) {
+    const int b = blockIdx.x;
+    if (b < n_groups * KV_SLOTS) {
+        const int g = b / KV_SLOTS, j = b - g * KV_SLOTS;
+        const StepGroup *G = &hblk->groups[g];
+        const int s = G->src[j], n_past = G->reorder_n_past;
+        if (G->reorder_flag == 0 || s < 0) return;
+        const int *old_idx = G->idx_old;
+        int *new_idx = G->idx_new;
+        for (int p = threadIdx.x; p <= n_past; p += 256) new_idx[j * n_text_ctx + p] = p < n_past ? old_idx[s * n_text_ctx + p] : j;
+    } else if (b < n_groups * KV_SLOTS + n_rows) {
+        const int i = b - n_groups * KV_SLOTS;
+        const long t = hblk->rows[i].token, p = hblk->rows[i].pos;
+        for (int e = threadIdx.x; e < d; e += 256) x[(long)i * d + e] = __uint_as_float((unsigned)te[t * d + e] << 16) + pe[p * d + e];
+    } else {
+        const int *src = reinterpret_cast<const int *>(hblk);
+        int *dst = reinterpret_cast<int *>(dblk);
+        for (int k = threadIdx.x; k < (int)(sizeof(StepBlock) / sizeof(int)); k += 256) dst[k] = src[k];
+    }
+}
 
 }  // namespace
 
 // Tile sizes per class (measured, DESIGN.md §4 rule 3): 8-feature tiles (twice the workgroups) for the projections of
 // at most d features (cross-q, attention outputs, fc2), 16 for qkv, 32-feature workgroups (two tiles, half the LayerNorm
-// passes) for fc1.
-void launch_proj_wg(const GemvArgs &a, hipStream_t st) {
-    MW_CHECK(a.x && a.W && a.out && a.n >= 1 && a.n <= 5, "proj_wg: 1..5 rows");
+// passes) for fc1.  Rows: kernels are instantiated for 1, 5 (beam step) and 16 (batched step) rows.
+namespace {
+void launch_proj_impl(const GemvArgs &a, const StepRow *rows, long kv_layer_off, hipStream_t st) {
+    MW_CHECK(a.x && a.W && a.out && a.n >= 1 && a.n <= STEP_MAX_ROWS, "proj_wg: 1..16 rows");
     MW_CHECK(a.N % 32 == 0 && a.K % 32 == 0 && a.ldx == a.K && !a.d_rows, "proj_wg: shape");
     const bool ln = a.ln_w != nullptr;
     Proj p{(const bf16_t *)a.W, a.bias, a.N, a.K};
     Epi e{};
+    e.rows = rows;
+    e.kv_layer_off = kv_layer_off;
     const dim3 block(MT);
-#define MW_PROJ_LN(NBv, EPIv)                                                                                                       \
+#define MW_PROJ_LN(NBv, EPIv, DESCv)                                                                                                \
     do {                                                                                                                            \
         if (a.N <= 1280)                                                                                                            \
-            hipLaunchKernelGGL((proj_ln_tile_kernel<NBv, EPIv, 8>), dim3(a.N / 8), block, 0, st, p, (const float *)a.x, a.ln_w, a.ln_b, \
-                               a.n, e);                                                                                             \
+            hipLaunchKernelGGL((proj_ln_tile_kernel<NBv, EPIv, 8, DESCv>), dim3(a.N / 8), block, 0, st, p, (const float *)a.x, a.ln_w, \
+                               a.ln_b, a.n, e);                                                                                     \
         else if (a.N > 4096)                                                                                                        \
-            hipLaunchKernelGGL((proj_ln_tile_kernel<NBv, EPIv, 32>), dim3(a.N / 32), block, 0, st, p, (const float *)a.x, a.ln_w,   \
-                               a.ln_b, a.n, e);                                                                                     \
+            hipLaunchKernelGGL((proj_ln_tile_kernel<NBv, EPIv, 32, DESCv>), dim3(a.N / 32), block, 0, st, p, (const float *)a.x,    \
+                               a.ln_w, a.ln_b, a.n, e);                                                                             \
         else                                                                                                                        \
-            hipLaunchKernelGGL((proj_ln_tile_kernel<NBv, EPIv, 16>), dim3(a.N / 16), block, 0, st, p, (const float *)a.x, a.ln_w,   \
-                               a.ln_b, a.n, e);                                                                                     \
+            hipLaunchKernelGGL((proj_ln_tile_kernel<NBv, EPIv, 16, DESCv>), dim3(a.N / 16), block, 0, st, p, (const float *)a.x,    \
+                               a.ln_w, a.ln_b, a.n, e);                                                                             \
     } while (0)
-#define MW_PROJ_LN_NB(EPIv)               \
-    do {                                   \
-        if (a.n == 1) MW_PROJ_LN(1, EPIv); \
-        else MW_PROJ_LN(5, EPIv);          \
+#define MW_PROJ_LN_NB(EPIv, DESCv)                     \
+    do {                                                \
+        if (a.n == 1) MW_PROJ_LN(1, EPIv, DESCv);       \
+        else if (a.n <= 5) MW_PROJ_LN(5, EPIv, DESCv);  \
+        else MW_PROJ_LN(16, EPIv, DESCv);               \
     } while (0)
     if (ln) MW_CHECK(a.ln_b && a.K <= 256 * LN_MAX_F4, "proj_wg: LayerNorm classes need K <= 1280");
     if (a.qkv) {
         MW_CHECK(ln && a.N == 3 * a.K && a.ldo == a.K && a.kv_t == DType::BF16, "proj_wg: qkv class");
+        MW_CHECK(rows || (a.kcache && a.vcache && a.d_slot && a.d_pos), "proj_wg: qkv class needs a cache");
         e.q = a.out; e.kc = (bf16_t *)a.kcache; e.vc = (bf16_t *)a.vcache; e.slot = a.d_slot; e.pos = a.d_pos; e.TC = a.n_text_ctx;
         e.d = a.K; e.qk_scale = a.qk_scale;
-        MW_PROJ_LN_NB(EPI_QKV);
+        if (rows) MW_PROJ_LN_NB(EPI_QKV, true);
+        else MW_PROJ_LN_NB(EPI_QKV, false);
     } else if (ln && a.act == ACT_GELU) {
         MW_CHECK(!a.R, "proj_wg: fc1 class");
         e.hout = (bf16_t *)a.out; e.fout = a.out; e.ldo = (int)a.ldo;
-        if (a.out_bf16) MW_PROJ_LN_NB(EPI_GELU_BF16);
-        else MW_PROJ_LN_NB(EPI_GELU_F32);
+        if (a.out_bf16) MW_PROJ_LN_NB(EPI_GELU_BF16, false);
+        else MW_PROJ_LN_NB(EPI_GELU_F32, false);
     } else if (ln) {
         MW_CHECK(!a.R && a.ldo == a.N && a.act == ACT_NONE, "proj_wg: cross-q class");
         e.fout = a.out; e.scale = a.out_scale;
-        MW_PROJ_LN_NB(EPI_SCALE);
+        MW_PROJ_LN_NB(EPI_SCALE, false);
     } else {
         MW_CHECK(a.x_bf16 && a.R && a.ldo == a.N && a.act == ACT_NONE && a.out_scale == 1.0f, "proj_wg: residual class");
         e.res = a.R; e.xout = a.out;
@@ -763,12 +873,16 @@ void launch_proj_wg(const GemvArgs &a, hipStream_t st) {
         MW_CHECK(a.K == 256 * ch * spc && spc >= 2 && spc <= 5, "proj_wg: residual class needs K = 256 * {1,4} * {2..5}");
 #define MW_RES(NBv, SPCv, CHv) \
     hipLaunchKernelGGL((proj_res_tile_kernel<NBv, SPCv, CHv, 8>), dim3(a.N / 8), block, 0, st, p, (const bf16_t *)a.x, a.n, e)
-#define MW_RES_SPC(SPCv)                                    \
-    do {                                                     \
-        if (a.n == 1 && ch == 1) MW_RES(1, SPCv, 1);         \
-        else if (a.n == 1) MW_RES(1, SPCv, 4);               \
-        else if (ch == 1) MW_RES(5, SPCv, 1);                \
-        else MW_RES(5, SPCv, 4);                             \
+#define MW_RES_CH(NBv, SPCv)              \
+    do {                                   \
+        if (ch == 1) MW_RES(NBv, SPCv, 1); \
+        else MW_RES(NBv, SPCv, 4);         \
+    } while (0)
+#define MW_RES_SPC(SPCv)                         \
+    do {                                          \
+        if (a.n == 1) MW_RES_CH(1, SPCv);         \
+        else if (a.n <= 5) MW_RES_CH(5, SPCv);    \
+        else MW_RES_CH(16, SPCv);                 \
     } while (0)
         switch (spc) {
         case 2: MW_RES_SPC(2); break;
@@ -777,16 +891,63 @@ void launch_proj_wg(const GemvArgs &a, hipStream_t st) {
         default: MW_RES_SPC(5); break;
         }
 #undef MW_RES_SPC
+#undef MW_RES_CH
 #undef MW_RES
     }
 #undef MW_PROJ_LN_NB
 #undef MW_PROJ_LN
     MW_HIP(hipGetLastError());
 }
+}  // namespace
+
+void launch_proj_wg(const GemvArgs &a, hipStream_t st) {
+    MW_CHECK(a.n <= 5, "proj_wg: 1..5 rows");
+    launch_proj_impl(a, nullptr, 0, st);
+}
+
+void launch_proj_batch(const GemvArgs &a, const StepBlock *blk, long kv_layer_off, hipStream_t st) {
+    MW_CHECK(blk != nullptr, "proj_batch: no step block");
+    launch_proj_impl(a, blk->rows, kv_layer_off, st);
+}
+
+void launch_step_begin_batch(const StepBlock *h_block_dev, StepBlock *d_block, int n_rows, int n_groups, int n_text_ctx,
+                             const void *tok_emb, const float *pos_emb, float *x, int d, hipStream_t st) {
+    MW_CHECK(h_block_dev && d_block && n_rows >= 1 && n_rows <= STEP_MAX_ROWS && n_groups >= 1 && n_groups <= STEP_MAX_GROUPS,
+             "step_begin_batch: rows / groups");
+    static_assert(sizeof(StepBlock) % sizeof(int) == 0, "StepBlock is copied int by int");
+    hipLaunchKernelGGL(step_begin_batch_kernel, dim3(n_groups * KV_SLOTS + n_rows + 1), dim3(256), 0, st, h_block_dev, d_block, n_rows,
+                       n_groups, n_text_ctx, (const bf16_t *)tok_emb, pos_emb, x, d);
+    MW_HIP(hipGetLastError());
+}
+
+void launch_self_attn_batch(const float *q, const StepBlock *blk, long kv_layer_off, void *out, int n, int H, int d, int n_text_ctx,
+                            hipStream_t st) {
+    MW_CHECK(blk && n >= 1 && n <= STEP_MAX_ROWS && H >= 1 && d == H * 64 && n_text_ctx <= TILE_TC_MAX, "self_attn_batch: shape");
+    hipLaunchKernelGGL((self_attn_lean_kernel<bf16_t, true>), dim3(n * H), dim3(MT), 0, st, q, (const bf16_t *)nullptr, (const bf16_t *)nullptr,
+                       (const int *)nullptr, (const int *)nullptr, (const int *)nullptr, blk->rows, kv_layer_off, (bf16_t *)out, H, d,
+                       n_text_ctx);
+    MW_HIP(hipGetLastError());
+}
+
+void launch_cross_attn_batch(const float *q, const StepBlock *blk, long k_off, long v_off, float *partial, void *out,
+                             unsigned *head_cnt, int n_rows, int n_groups, int H, int d, int n_ctx_max, int splits, hipStream_t st) {
+    MW_CHECK(blk && n_rows >= 1 && n_rows <= STEP_MAX_ROWS && n_groups >= 1 && n_groups <= STEP_MAX_GROUPS && d == H * 64,
+             "cross_attn_batch: shape");
+    MW_CHECK(splits >= 1 && splits <= CROSS_SPLITS_MAX && ceil_div(n_ctx_max, splits) <= XK, "cross_attn_batch: at most 128 keys per split");
+    const dim3 grid(n_groups * H * splits), block(MT);
+    // rows per request: <= 5 (beams of one stream) unless a prompt of up to 16 tokens rides in the step
+    if (n_rows <= 5)
+        hipLaunchKernelGGL((cross_attn_lean_kernel<5, bf16_t, true>), grid, block, 0, st, q, (const bf16_t *)nullptr, (const bf16_t *)nullptr,
+                           blk->groups, k_off, v_off, partial, (bf16_t *)out, head_cnt, 0, H, d, 0, splits);
+    else
+        hipLaunchKernelGGL((cross_attn_lean_kernel<16, bf16_t, true>), grid, block, 0, st, q, (const bf16_t *)nullptr, (const bf16_t *)nullptr,
+                           blk->groups, k_off, v_off, partial, (bf16_t *)out, head_cnt, 0, H, d, 0, splits);
+    MW_HIP(hipGetLastError());
+}
 
 bool logits_tile_supported(const GemvArgs &a) {
     const int nch = a.K / LKC;
-    return a.n >= 1 && a.n <= 5 && a.ln_w && a.ln_b && a.d_rows && a.K % LKC == 0 && a.ldx == a.K && !a.bias && !a.R &&
+    return a.n >= 1 && a.n <= STEP_MAX_ROWS && a.ln_w && a.ln_b && a.d_rows && a.K % LKC == 0 && a.ldx == a.K && !a.bias && !a.R &&
            a.act == ACT_NONE && a.out_scale == 1.0f && (nch == 3 || nch == 4 || nch == 6 || nch == 8 || nch == 10);
 }
 
@@ -796,10 +957,11 @@ void launch_logits_tile(const GemvArgs &a, hipStream_t st) {
 #define MW_LT(NBv, NCHv)                                                                                                     \
     hipLaunchKernelGGL((logits_tile_kernel<NBv, NCHv>), grid, block, 0, st, (const bf16_t *)a.W, a.x, a.d_rows, a.ln_w, a.ln_b, \
                        a.out, a.ldo, a.n, a.N)
-#define MW_LT_NB(NCHv)              \
-    do {                             \
-        if (a.n == 1) MW_LT(1, NCHv); \
-        else MW_LT(5, NCHv);          \
+#define MW_LT_NB(NCHv)                     \
+    do {                                    \
+        if (a.n == 1) MW_LT(1, NCHv);       \
+        else if (a.n <= 5) MW_LT(5, NCHv);  \
+        else MW_LT(16, NCHv);               \
     } while (0)
     switch (a.K / LKC) {
     case 3: MW_LT_NB(3); break;
@@ -817,11 +979,11 @@ void launch_self_attn_wg(const float *q, const void *kcache, const void *vcache,
                          const int *d_kv_idx, void *out, DType out_t, int n, int H, int d, int n_text_ctx, hipStream_t st) {
     MW_CHECK(n >= 1 && H >= 1 && d == H * 64 && n_text_ctx <= TILE_TC_MAX, "self_attn_wg: shape");
     if (out_t == DType::F32)
-        hipLaunchKernelGGL(self_attn_lean_kernel<float>, dim3(n * H), dim3(MT), 0, st, q, (const bf16_t *)kcache, (const bf16_t *)vcache,
-                           d_slot, d_pos, d_kv_idx, (float *)out, H, d, n_text_ctx);
+        hipLaunchKernelGGL((self_attn_lean_kernel<float, false>), dim3(n * H), dim3(MT), 0, st, q, (const bf16_t *)kcache, (const bf16_t *)vcache,
+                           d_slot, d_pos, d_kv_idx, (const StepRow *)nullptr, 0L, (float *)out, H, d, n_text_ctx);
     else
-        hipLaunchKernelGGL(self_attn_lean_kernel<bf16_t>, dim3(n * H), dim3(MT), 0, st, q, (const bf16_t *)kcache, (const bf16_t *)vcache,
-                           d_slot, d_pos, d_kv_idx, (bf16_t *)out, H, d, n_text_ctx);
+        hipLaunchKernelGGL((self_attn_lean_kernel<bf16_t, false>), dim3(n * H), dim3(MT), 0, st, q, (const bf16_t *)kcache, (const bf16_t *)vcache,
+                           d_slot, d_pos, d_kv_idx, (const StepRow *)nullptr, 0L, (bf16_t *)out, H, d, n_text_ctx);
     MW_HIP(hipGetLastError());
 }
 
@@ -833,8 +995,8 @@ void launch_cross_attn_wg(const float *q, const void *kc, const void *vc, float 
     MW_CHECK(per <= XK, "cross_attn_wg: at most 128 keys per split");
     const dim3 grid(H * splits), block(MT);
 #define MW_CROSS(NBv, OTv)                                                                                                \
-    hipLaunchKernelGGL((cross_attn_lean_kernel<NBv, OTv>), grid, block, 0, st, q, (const bf16_t *)kc, (const bf16_t *)vc, \
-                       partial, (OTv *)out, head_cnt, n, H, d, n_ctx, splits, per)
+    hipLaunchKernelGGL((cross_attn_lean_kernel<NBv, OTv, false>), grid, block, 0, st, q, (const bf16_t *)kc, (const bf16_t *)vc, \
+                       (const StepGroup *)nullptr, 0L, 0L, partial, (OTv *)out, head_cnt, n, H, d, n_ctx, splits)
     if (out_t == DType::F32) {
         if (n == 1) MW_CROSS(1, float);
         else MW_CROSS(5, float);

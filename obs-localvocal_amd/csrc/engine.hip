@@ -40,6 +40,7 @@ Context::~Context() {
         if (p) (void)hipFree(p);
     if (h_ints) (void)hipHostFree(h_ints);
     if (ev_staging) (void)hipEventDestroy(ev_staging);
+    if (ev_ready) (void)hipEventDestroy(ev_ready);
     if (h_row_state) (void)hipHostFree(h_row_state);
     if (h_row_res) (void)hipHostFree(h_row_res);
     for (hipEvent_t e : prof_ev) (void)hipEventDestroy(e);
@@ -142,7 +143,12 @@ std::unique_ptr<Context> create_context_impl(const unsigned char *data, size_t s
         dev_alloc(c->d_head_cnt, 64);
         MW_HIP(hipMemsetAsync(c->d_head_cnt, 0, 64 * sizeof(unsigned), c->st));
         c->tile_step = true;
+        // decode steps of the contexts that share these weights are batched by one hub per upload (engine.hpp)
+        c->use_hub = getenv("MI355_WHISPER_NO_BATCH") == nullptr;
+        if (c->use_hub && !c->model.hub) c->model.hub = create_hub(c->model, device, c->use_graphs);
     }
+    MW_HIP(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
+    c->st_dirty = true;
     MW_HIP(hipStreamSynchronize(c->st));
     log_msg(LOG_INFO, "mi355_whisper: %s (%zu params, %s weights, %.1f MB arena) on device %d (%s)\n",
             share ? "stream context on shared weights" : "model loaded", c->model.n_params, wt == DType::F32 ? "fp32" : "bf16",
@@ -150,6 +156,310 @@ std::unique_ptr<Context> create_context_impl(const unsigned char *data, size_t s
     return c;
 }
 }  // namespace
+
+
+// ------------------------------------------------------------------------------------------
+// the hub: one batched decode step over the rows of several contexts (engine.hpp)
+// ------------------------------------------------------------------------------------------
+Hub::~Hub() {
+    (void)hipSetDevice(device);
+    if (st) (void)hipStreamSynchronize(st);
+    void *ptrs[] = {d_blk, d_x, d_q, d_part, d_logits, d_work, d_attd, d_ffd, d_head_cnt, d_suppress};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (h_blk) (void)hipHostFree(h_blk);
+    if (h_res) (void)hipHostFree(h_res);
+    for (auto &kv : graphs) (void)hipGraphExecDestroy(kv.second);
+    if (st) (void)hipStreamDestroy(st);
+}
+
+std::shared_ptr<Hub> create_hub(const Model &m, int device, bool use_graphs) {
+    std::shared_ptr<Hub> h(new Hub());
+    h->device = device;
+    h->m = m;
+    h->m.arena_owner.reset();  // the hub is owned by the models that point to it, never the other way round
+    h->m.mel_tab_owner.reset();
+    h->m.hub.reset();
+    h->use_graphs = use_graphs;
+    const HParams &hp = m.hp;
+    const size_t d = hp.n_text_state, H = hp.n_text_head, nv = hp.n_vocab, R = STEP_MAX_ROWS;
+    MW_HIP(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
+    MW_HIP(hipHostMalloc((void **)&h->h_blk, sizeof(StepBlock)));
+    memset(h->h_blk, 0, sizeof(StepBlock));
+    MW_HIP(hipHostGetDevicePointer((void **)&h->h_blk_dev, h->h_blk, 0));
+    MW_HIP(hipHostMalloc((void **)&h->h_res, R * sizeof(LogitsRowResult)));
+    MW_HIP(hipHostGetDevicePointer((void **)&h->h_res_dev, h->h_res, 0));
+    dev_alloc(h->d_blk, 1);
+    dev_alloc(h->d_x, R * d);
+    dev_alloc(h->d_q, R * d);
+    dev_alloc_bytes(h->d_attd, R * d * 2);
+    dev_alloc_bytes(h->d_ffd, R * 4 * d * 2);
+    dev_alloc(h->d_part, R * H * CROSS_SPLITS_MAX * 66);
+    dev_alloc(h->d_logits, R * nv);
+    dev_alloc(h->d_work, process_logits_work_floats((int)R, (int)nv));
+    dev_alloc(h->d_suppress, nv);
+    dev_alloc(h->d_head_cnt, (size_t)STEP_MAX_GROUPS * 64);
+    MW_HIP(hipMemsetAsync(h->d_head_cnt, 0, (size_t)STEP_MAX_GROUPS * 64 * sizeof(unsigned), h->st));
+    MW_HIP(hipStreamSynchronize(h->st));
+    return h;
+}
+
+void Hub::submit(StepRequest &r) {
+    std::unique_lock<std::mutex> lk(mu);
+    queue.push_back(&r);
+    while (!r.done) {
+        if (busy) {
+            cv.wait(lk);
+            continue;
+        }
+        // the hub is idle: this thread leads the next step.  It takes the oldest request and every later one that can
+        // share its step (same rules, rows / groups / logits rows / sampler rows within the step's limits), in order.
+        std::vector<StepRequest *> batch;
+        int rows = 0, lrows = 0, srows = 0;
+        StepRequest *first = queue.front();
+        for (auto it = queue.begin(); it != queue.end();) {
+            StepRequest *q = *it;
+            const int sr = q->sample ? q->c->ps_n : 0;
+            const bool fits = batch.empty() || (!first->solo && !q->solo && q->rules_key == first->rules_key &&
+                                                (int)batch.size() < STEP_MAX_GROUPS && rows + q->n <= STEP_MAX_ROWS &&
+                                                lrows + q->n_logit_rows <= STEP_MAX_ROWS && srows + sr <= STEP_MAX_ROWS);
+            if (fits) {
+                batch.push_back(q);
+                rows += q->n;
+                lrows += q->n_logit_rows;
+                srows += sr;
+                it = queue.erase(it);
+            } else {
+                ++it;
+            }
+        }
+        busy = true;
+        lk.unlock();
+        std::exception_ptr err;
+        try {
+            run(batch);
+        } catch (...) {
+            err = std::current_exception();
+            (void)hipStreamSynchronize(st);  // nothing of the failed step may still be running when its requests return
+        }
+        lk.lock();
+        for (StepRequest *q : batch) {
+            q->err = err;
+            q->done = true;
+        }
+        n_steps += 1;
+        n_rows += (unsigned long long)rows;
+        n_requests += batch.size();
+        busy = false;
+        cv.notify_all();
+    }
+    lk.unlock();
+    if (r.err) std::rethrow_exception(r.err);
+}
+
+void Hub::run(const std::vector<StepRequest *> &batch) {
+    MW_HIP(hipSetDevice(device));
+    const HParams &hp = m.hp;
+    const int d = hp.n_text_state, H = hp.n_text_head, TC = hp.n_text_ctx, T = hp.n_audio_ctx, nv = hp.n_vocab;
+    StepBlock &B = *h_blk;
+    int R = 0, G = 0, LR = 0, SR = 0, n_ctx_max = 1;
+    Context *lead = batch[0]->c;
+    const bool sample = batch[0]->sample;
+    for (StepRequest *q : batch) {
+        Context &c = *q->c;
+        MW_CHECK(c.model.wt == DType::BF16 && c.model.arena == m.arena, "hub: context does not share the hub's weights");
+        if (c.st_dirty) {  // the step reads what the context's own stream is still producing (encoder output, cleared tables)
+            MW_HIP(hipStreamWaitEvent(st, c.ev_ready, 0));
+            c.st_dirty = false;
+        }
+        StepGroup &g = B.groups[G];
+        g.cross = (const bf16_t *)c.d_cross;
+        g.idx_old = c.d_kv_idx[c.kv_cur ^ 1];
+        g.idx_new = c.d_kv_idx[c.kv_cur];
+        g.row0 = R;
+        g.nrows = q->n;
+        g.n_ctx = c.n_ctx_cur;
+        g.reorder_flag = c.reorder_pending ? 1 : 0;
+        g.reorder_n_past = c.reorder_n_past;
+        for (int j = 0; j < KV_SLOTS; ++j) g.src[j] = c.reorder_pending ? c.reorder_src[j] : -1;
+        g.pad = 0;
+        c.reorder_pending = false;
+        n_ctx_max = std::max(n_ctx_max, c.n_ctx_cur);
+        for (int i = 0; i < q->n; ++i) {
+            StepRow &r = B.rows[R + i];
+            r.kself = (bf16_t *)c.d_kself;
+            r.vself = (bf16_t *)c.d_vself;
+            r.kv_idx = c.d_kv_idx[c.kv_cur];
+            r.slot = q->slot[i];
+            r.pos = q->pos[i];
+            r.token = q->tokens[i];
+            r.group = G;
+        }
+        for (int i = 0; i < q->n_logit_rows; ++i) B.logit_rows[LR + i] = R + q->logit_rows[i];
+        if (q->sample) {
+            for (int i = 0; i < c.ps_n; ++i) {
+                B.rs[SR + i] = c.h_row_state[i];
+                B.rs[SR + i].logits_row = LR + c.h_row_state[i].logits_row;
+            }
+            SR += c.ps_n;
+        }
+        LR += q->n_logit_rows;
+        R += q->n;
+        G += 1;
+    }
+    B.n_rows = R;
+    B.n_groups = G;
+    const int splits = std::min(CROSS_SPLITS_MAX, ceil_div(n_ctx_max, 128));
+    MW_CHECK(ceil_div(n_ctx_max, splits) <= 128, "hub: audio context too long for the cross-attention tiles");
+    LogitsParams lp{};
+    if (sample) {
+        lp = lead->ps_lp;
+        if (suppress_key != lead->suppress_key || suppress_key.empty()) {
+            MW_HIP(hipMemcpyAsync(d_suppress, lead->d_suppress, (size_t)nv, hipMemcpyDeviceToDevice, st));
+            suppress_key = lead->suppress_key;
+        }
+    }
+    // measurement hooks of a solo request's context (mw_profile_begin / mw_set_duplicate_class)
+    Context *pc = batch[0]->solo ? lead : nullptr;
+    const int prof_tag = pc ? pc->prof_tag : -1, dup_tag = pc ? pc->dup_tag : -1;
+    const size_t kv_layer = (size_t)KV_SLOTS * TC * d;
+    const float qk_scale = powf(64.0f, -0.25f);
+    auto enqueue = [&]() {
+        launch_step_begin_batch(h_blk_dev, d_blk, R, G, TC, m.tok_emb, m.dec_pe, d_x, d, st);
+        auto bracket = [&](int tag, auto &&launch) {
+            const bool prof = pc && tag == prof_tag && pc->prof_n + 2 <= (int)pc->prof_ev.size();
+            if (prof) MW_HIP(hipEventRecord(pc->prof_ev[pc->prof_n++], st));
+            launch();
+            if (prof) MW_HIP(hipEventRecord(pc->prof_ev[pc->prof_n++], st));
+        };
+        auto proj = [&](GemvArgs g, long kv_off) {
+            bracket(g.tag, [&]() { launch_proj_batch(g, d_blk, kv_off, st); });
+            if (g.tag == dup_tag && prof_tag < 0) {  // measurement: the class's launches are issued twice
+                if (g.R && g.out == g.R) g.out = d_part;
+                launch_proj_batch(g, d_blk, kv_off, st);
+            }
+        };
+        for (int l = 0; l < hp.n_text_layer; ++l) {
+            const DecLayer &e = m.dec[l];
+            const long kv_off = (long)(l * kv_layer);
+            {
+                GemvArgs g;  // LN + Q|K|V; K and V go straight into each row's cache
+                g.x = d_x; g.ldx = d; g.n = R; g.W = e.qkv_w; g.bias = e.qkv_b; g.N = 3 * d; g.K = d;
+                g.ln_w = e.ln1_w; g.ln_b = e.ln1_b; g.out = d_q; g.ldo = d; g.qkv = 1; g.qk_scale = qk_scale;
+                g.kv_t = DType::BF16; g.n_text_ctx = TC; g.tag = GEMV_QKV;
+                proj(g, kv_off);
+            }
+            bracket(GEMV_N_TAGS, [&]() { launch_self_attn_batch(d_q, d_blk, kv_off, d_attd, R, H, d, TC, st); });
+            if (dup_tag == GEMV_N_TAGS && prof_tag < 0) launch_self_attn_batch(d_q, d_blk, kv_off, d_attd, R, H, d, TC, st);
+            {
+                GemvArgs g;
+                g.x = (const float *)d_attd; g.x_bf16 = 1; g.ldx = d; g.n = R; g.W = e.out_w; g.bias = e.out_b; g.N = d; g.K = d;
+                g.out = d_x; g.ldo = d; g.R = d_x; g.tag = GEMV_ATTN_OUT;
+                proj(g, 0);
+            }
+            {
+                GemvArgs g;  // LN + cross query (scaled)
+                g.x = d_x; g.ldx = d; g.n = R; g.W = e.cq_w; g.bias = e.cq_b; g.N = d; g.K = d;
+                g.ln_w = e.lnc_w; g.ln_b = e.lnc_b; g.out = d_q; g.ldo = d; g.out_scale = qk_scale; g.tag = GEMV_CROSS_Q;
+                proj(g, 0);
+            }
+            const long k_off = (long)l * 2 * T * d, v_off = k_off + (long)T * d;
+            bracket(GEMV_N_TAGS + 1, [&]() {
+                launch_cross_attn_batch(d_q, d_blk, k_off, v_off, d_part, d_attd, d_head_cnt, R, G, H, d, n_ctx_max, splits, st);
+            });
+            if (dup_tag == GEMV_N_TAGS + 1 && prof_tag < 0)
+                launch_cross_attn_batch(d_q, d_blk, k_off, v_off, d_part, d_attd, d_head_cnt, R, G, H, d, n_ctx_max, splits, st);
+            {
+                GemvArgs g;
+                g.x = (const float *)d_attd; g.x_bf16 = 1; g.ldx = d; g.n = R; g.W = e.co_w; g.bias = e.co_b; g.N = d; g.K = d;
+                g.out = d_x; g.ldo = d; g.R = d_x; g.tag = GEMV_ATTN_OUT;
+                proj(g, 0);
+            }
+            {
+                GemvArgs g;
+                g.x = d_x; g.ldx = d; g.n = R; g.W = e.fc1_w; g.bias = e.fc1_b; g.N = 4 * d; g.K = d;
+                g.ln_w = e.ln2_w; g.ln_b = e.ln2_b; g.act = ACT_GELU; g.out = (float *)d_ffd; g.out_bf16 = 1; g.ldo = 4 * d; g.tag = GEMV_FC1;
+                proj(g, 0);
+            }
+            {
+                GemvArgs g;
+                g.x = (const float *)d_ffd; g.x_bf16 = 1; g.ldx = 4 * d; g.n = R; g.W = e.fc2_w; g.bias = e.fc2_b; g.N = d; g.K = 4 * d;
+                g.out = d_x; g.ldo = d; g.R = d_x; g.tag = GEMV_FC2;
+                proj(g, 0);
+            }
+        }
+        if (LR > 0) {
+            GemvArgs g;  // final LN + tied-embedding logits, only for the rows that are sampled from
+            g.x = d_x; g.ldx = d; g.n = LR; g.W = m.tok_emb; g.N = nv; g.K = d;
+            g.ln_w = m.dec_ln_w; g.ln_b = m.dec_ln_b; g.out = d_logits; g.ldo = nv; g.d_rows = d_blk->logit_rows;
+            g.tag = GEMV_LOGITS;
+            MW_CHECK(logits_tile_supported(g), "hub: logits projection shape");
+            bracket(GEMV_LOGITS, [&]() { launch_logits_tile(g, st); });
+            if (dup_tag == GEMV_LOGITS && prof_tag < 0) launch_logits_tile(g, st);
+        }
+        if (sample && SR > 0)  // results (100 bytes per row) are stored straight into pinned host memory
+            launch_process_logits(d_logits, nv, d_suppress, lp, d_blk->rs, h_res_dev, SR, d_work, nullptr, nullptr, nullptr, st);
+    };
+    if (!use_graphs || prof_tag >= 0 || (pc && !pc->use_graphs)) {
+        enqueue();
+    } else {
+        uint64_t key = (uint64_t)R | ((uint64_t)G << 8) | ((uint64_t)LR << 16) | ((uint64_t)SR << 24) | ((uint64_t)splits << 32) |
+                       ((uint64_t)(dup_tag + 1) << 40) | ((uint64_t)(sample ? 1 : 0) << 48);
+        if (sample) {  // the rules' parameters are kernel arguments of the captured nodes: part of the key (FNV-1a over their bytes)
+            uint64_t h = 1469598103934665603ull;
+            for (size_t i = 0; i < sizeof(lp); ++i) h = (h ^ ((const unsigned char *)&lp)[i]) * 1099511628211ull;
+            key ^= (h | 1ull) * 0x9e3779b97f4a7c15ull;
+        }
+        auto it = graphs.find(key);
+        if (it != graphs.end()) {
+            auto pos = std::find(graph_lru.begin(), graph_lru.end(), key);
+            if (pos != graph_lru.end() && pos + 1 != graph_lru.end()) std::rotate(pos, pos + 1, graph_lru.end());
+        } else {
+            if (graphs.size() >= 96) {  // bounded cache: evict the least recently used graph
+                const uint64_t old = graph_lru.front();
+                graph_lru.erase(graph_lru.begin());
+                auto ot = graphs.find(old);
+                if (ot != graphs.end()) {
+                    (void)hipGraphExecDestroy(ot->second);
+                    graphs.erase(ot);
+                }
+            }
+            hipGraph_t graph = nullptr;
+            MW_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            try {
+                enqueue();
+            } catch (...) {
+                (void)hipStreamEndCapture(st, &graph);
+                if (graph) (void)hipGraphDestroy(graph);
+                throw;
+            }
+            MW_HIP(hipStreamEndCapture(st, &graph));
+            hipGraphExec_t exec = nullptr;
+            MW_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+            MW_HIP(hipGraphDestroy(graph));
+            it = graphs.emplace(key, exec).first;
+            graph_lru.push_back(key);
+        }
+        MW_HIP(hipGraphLaunch(it->second, st));
+    }
+    {   // logits rows of the requests that read them back (stage calls, language detection, unfused sampler)
+        int lr = 0;
+        for (StepRequest *q : batch) {
+            if (q->keep_logits && q->n_logit_rows > 0)
+                MW_HIP(hipMemcpyAsync(q->c->d_logits, d_logits + (size_t)lr * nv, (size_t)q->n_logit_rows * nv * sizeof(float),
+                                      hipMemcpyDeviceToDevice, st));
+            lr += q->n_logit_rows;
+        }
+    }
+    MW_HIP(hipStreamSynchronize(st));
+    int sr = 0;
+    for (StepRequest *q : batch) {
+        if (!q->sample) continue;
+        Context &c = *q->c;
+        memcpy(c.h_row_res, h_res + sr, (size_t)c.ps_n * sizeof(LogitsRowResult));
+        sr += c.ps_n;
+    }
+}
 
 // ------------------------------------------------------------------------------------------
 // mel (A.2)
@@ -292,6 +602,7 @@ void encode(Context &c, int seek) {
         v.bias = m.ckv_b + d; v.sB1 = 2L * d; v.alpha = 1.0f;
         gemm(v, wt, wt, st);
     }
+    c.st_dirty = true;
     c.tm.n_encode++;
     c.tm.encode_ms += now_ms() - t0;
 }
@@ -305,6 +616,7 @@ void kv_clear(Context &c) {
     MW_HIP(hipMemsetAsync(c.d_kv_idx[0], 0, bytes, c.st));
     MW_HIP(hipMemsetAsync(c.d_kv_idx[1], 0, bytes, c.st));
     c.kv_cur = 0;
+    c.st_dirty = true;
 }
 
 namespace {
@@ -314,6 +626,7 @@ void flush_reorder(Context &c) {  // a deferred index-table update that no decod
     for (int j = 0; j < KV_SLOTS; ++j) b.src[j] = c.reorder_src[j];
     launch_kv_reorder(c.d_kv_idx[c.kv_cur ^ 1], c.d_kv_idx[c.kv_cur], b, c.reorder_n_past, c.model.hp.n_text_ctx, c.st);
     c.reorder_pending = false;
+    c.st_dirty = true;
 }
 }  // namespace
 
@@ -343,6 +656,27 @@ void decode(Context &c, const int *tokens, const int *pos, const int *slot, int 
         MW_CHECK(slot[i] >= 0 && slot[i] < KV_SLOTS, "decode: bad sequence slot");
     }
     for (int i = 0; i < n_logit_rows; ++i) MW_CHECK(logit_rows[i] >= 0 && logit_rows[i] < n, "decode: bad logits row");
+    if (c.tile_step && c.use_hub && c.model.hub && n <= STEP_MAX_ROWS && n_logit_rows <= STEP_MAX_ROWS &&
+        (!c.ps_armed || c.ps_n <= STEP_MAX_ROWS)) {
+        // batched path: the step runs on the hub of the contexts that share these weights, together with whatever other
+        // contexts have queued meanwhile (one pass over the weights for all their rows)
+        const double t0h = now_ms();
+        StepRequest r;
+        r.c = &c;
+        r.tokens = tokens; r.pos = pos; r.slot = slot; r.n = n;
+        r.logit_rows = logit_rows; r.n_logit_rows = n_logit_rows;
+        r.sample = c.ps_armed && c.fuse_sample && n_logit_rows > 0 && c.prof_tag < 0;
+        r.keep_logits = !r.sample && n_logit_rows > 0;
+        r.solo = c.prof_tag >= 0 || c.dup_tag >= 0 || !c.use_graphs;
+        if (r.sample) r.rules_key = std::string((const char *)&c.ps_lp, sizeof(c.ps_lp)) + "|" + c.suppress_key;
+        if (c.st_dirty) MW_HIP(hipEventRecord(c.ev_ready, c.st));
+        c.model.hub->submit(r);
+        c.ps_fused = r.sample;  // the results are in h_row_res already
+        c.n_logit_rows = n_logit_rows;
+        c.tm.n_decode++;
+        c.tm.decode_ms += now_ms() - t0h;
+        return;
+    }
     hipStream_t st = c.st;
     const bool tile = c.tile_step && n <= 5;  // bf16 rows between attention / MLP kernels and the residual projections
     const bool mf = tile;
@@ -542,6 +876,7 @@ void decode(Context &c, const int *tokens, const int *pos, const int *slot, int 
     }
     MW_HIP(hipEventRecord(c.ev_staging, st));
     c.staging_pending = true;
+    c.st_dirty = true;
     c.ps_fused = fuse && use_graph;
     c.n_logit_rows = n_logit_rows;
     c.tm.n_decode++;

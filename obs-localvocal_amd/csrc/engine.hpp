@@ -5,7 +5,11 @@
 
 #include "../../include/whisper.h"
 
+#include <condition_variable>
+#include <deque>
+#include <exception>
 #include <memory>
+#include <mutex>
 #include <random>
 #include <string>
 #include <vector>
@@ -41,6 +45,58 @@ struct Timings {
     double mel_ms = 0, encode_ms = 0, decode_ms = 0, sample_ms = 0, total_ms = 0;
     int n_encode = 0, n_decode = 0, n_sample = 0;
 };
+
+struct Context;
+
+// One decode call of one context, as the hub sees it (lives on the calling thread's stack until it is done).
+struct StepRequest {
+    Context *c = nullptr;
+    const int *tokens = nullptr, *pos = nullptr, *slot = nullptr;
+    int n = 0;
+    const int *logit_rows = nullptr;
+    int n_logit_rows = 0;
+    bool sample = false;       // the context's prepared rules + sampler rows ride in the step (results -> c->h_row_res)
+    bool keep_logits = false;  // copy the request's logits rows into c->d_logits (stage calls, language detection, unfused sampler)
+    bool solo = false;         // measurement hooks armed on the context: never batched with other requests
+    std::string rules_key;     // requests share a step only when their rules + sampler parameters are identical
+    bool done = false;
+    std::exception_ptr err;
+};
+
+// The batcher of decode steps for the contexts (streams, OBS sources) that share one upload of the weights on one GPU.
+// LocalVocal runs one worker thread per filter, each calling whisper_full on its own context
+// (/root/reference/src/whisper-utils/whisper-processing.cpp:361-431, whisper-utils.cpp:49-50); their decode calls meet
+// here: the first thread to find the hub idle becomes the leader, takes the requests queued so far (up to STEP_MAX_ROWS
+// rows), runs ONE step over all their rows — one pass over the weights — and hands every request its rows' results.
+// Requests that arrive while a step runs form the next step (no timed waiting: one stream alone is never delayed).
+struct Hub {
+    int device = 0;
+    hipStream_t st = nullptr;
+    Model m;  // non-owning view of the weights (owners reset: the hub is owned BY the models that point to it)
+    // step block: pinned host copy (and its device view) + the device copy the kernels read
+    StepBlock *h_blk = nullptr, *h_blk_dev = nullptr, *d_blk = nullptr;
+    float *d_x = nullptr, *d_q = nullptr, *d_part = nullptr, *d_logits = nullptr, *d_work = nullptr;
+    void *d_attd = nullptr, *d_ffd = nullptr;
+    unsigned *d_head_cnt = nullptr;
+    LogitsRowResult *h_res = nullptr, *h_res_dev = nullptr;  // pinned: the sampler stores its results straight into it
+    unsigned char *d_suppress = nullptr;  // the suppression mask of the last step's rules (copied from its leader when the key changes)
+    std::string suppress_key;
+    bool use_graphs = true;
+    std::unordered_map<uint64_t, hipGraphExec_t> graphs;
+    std::vector<uint64_t> graph_lru;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<StepRequest *> queue;
+    bool busy = false;
+    // statistics (mw_hub_stats)
+    unsigned long long n_steps = 0, n_rows = 0, n_requests = 0;
+
+    ~Hub();
+    void submit(StepRequest &r);  // blocks until the request's step has run; rethrows its error
+  private:
+    void run(const std::vector<StepRequest *> &batch);
+};
+std::shared_ptr<Hub> create_hub(const Model &m, int device, bool use_graphs);
 
 struct Context {
     int device = 0;
@@ -111,6 +167,10 @@ struct Context {
     // matrix-core tile kernels of the beam step (dec_tile.hip): bf16 weights, <= 5 rows, 64-wide heads, d % 256 == 0
     bool tile_step = false;
     unsigned *d_head_cnt = nullptr;  // per-head arrival counters of the fused cross-attention combine
+    // batched path: work enqueued on `st` that a hub step must wait for (encoder, cache clears, a long prompt's prefill)
+    bool st_dirty = false;
+    hipEvent_t ev_ready = nullptr;
+    bool use_hub = true;  // MI355_WHISPER_NO_BATCH: every context runs its own steps (the per-context graph path)
 
     ~Context();
 };

@@ -94,6 +94,43 @@ constexpr int DEC_MAX_ROWS = 8;      // activation rows one weight pass serves
 constexpr int KV_SLOTS = 8;          // physical self-KV slots per stream (= WHISPER_MAX_DECODERS)
 constexpr int CROSS_SPLITS_MAX = 16;
 
+// A batched step: up to STEP_MAX_ROWS rows that ride in M of one 16-row MFMA tile, taken from up to STEP_MAX_GROUPS
+// requests (one request = the rows of one stream context: its beams, or the tokens of a short prompt).  Everything that
+// differs per row or per request travels in a StepBlock in device memory, so one captured graph serves any mix of
+// contexts with the same (rows, groups, logits rows) shape.
+constexpr int STEP_MAX_ROWS = 16;
+constexpr int STEP_MAX_GROUPS = 16;
+struct StepRow {
+    bf16_t *kself, *vself;  // self K / V cache of the row's context, layer 0: [L][KV_SLOTS][n_text_ctx][d]
+    const int *kv_idx;      // the context's current index table [KV_SLOTS][n_text_ctx]
+    int slot, pos, token, group;
+};
+struct StepGroup {
+    const bf16_t *cross;    // cross K | V of the request's context: [L][2][n_audio_ctx][d]
+    const int *idx_old;     // beam reshuffle of the index table (reorder_flag): new[j][p] = old[src[j]][p], new[j][n_past] = j
+    int *idx_new;
+    int row0, nrows, n_ctx;
+    int reorder_flag, reorder_n_past;
+    int src[KV_SLOTS];
+    int pad;
+};
+// per decoder row, uploaded per step (rules + samplers, logits.hip)
+constexpr int MAX_CAND = 8;
+struct LogitsRowState {
+    int logits_row;       // row of the logits matrix
+    int n_sampled;        // tokens sampled so far (0 => initial)
+    int last_is_ts, penult_is_ts;
+    int has_ts, seek_delta;
+    double u[MAX_CAND];   // uniform draws for the samplers
+};
+struct StepBlock {  // pinned host memory -> device memory by the step's first kernel
+    StepRow rows[STEP_MAX_ROWS];
+    StepGroup groups[STEP_MAX_GROUPS];
+    int logit_rows[STEP_MAX_ROWS];
+    LogitsRowState rs[STEP_MAX_ROWS];
+    int n_rows, n_groups, pad[2];
+};
+
 // x[i][:] = tok_emb[token[i]][:] + pos_emb[pos[i]][:]
 void launch_embed(const int *d_tokens, const int *d_pos, const void *tok_emb, DType wt, const float *pos_emb,
                   float *x, int n, int d, hipStream_t st);
@@ -158,6 +195,20 @@ constexpr int TILE_TC_MAX = 448;         // text positions one self-attention pa
 // item is issued up front; the cross kernel's last split per head combines the partial softmaxes itself
 // (head_cnt: H zeroed counters, left zeroed)
 // logits projection (final LayerNorm + tied embedding) on matrix-core tiles: bf16 weights, <= 5 gathered rows
+// ---- batched step (StepBlock-driven; bf16, <= STEP_MAX_ROWS rows) ----
+// head of the step: block from pinned host memory (device view) -> per-request index-table updates, token embeddings of
+// the rows into x, and the block's copy into device memory
+void launch_step_begin_batch(const StepBlock *h_block_dev, StepBlock *d_block, int n_rows, int n_groups, int n_text_ctx,
+                             const void *tok_emb, const float *pos_emb, float *x, int d, hipStream_t st);
+// GemvArgs contract of launch_proj_wg for n <= STEP_MAX_ROWS rows; the qkv class writes K / V through blk->rows[i] + kv_layer_off
+// (element offset of the layer inside a context's cache)
+void launch_proj_batch(const GemvArgs &a, const StepBlock *blk, long kv_layer_off, hipStream_t st);
+void launch_self_attn_batch(const float *q, const StepBlock *blk, long kv_layer_off, void *out, int n, int H, int d, int n_text_ctx,
+                            hipStream_t st);
+// cross-attention of every request's rows over its own context's K / V (element offsets of the layer's K and V inside
+// a context's cross buffer); head_cnt: n_groups * H zeroed counters, left zeroed
+void launch_cross_attn_batch(const float *q, const StepBlock *blk, long k_off, long v_off, float *partial, void *out,
+                             unsigned *head_cnt, int n_rows, int n_groups, int H, int d, int n_ctx_max, int splits, hipStream_t st);
 bool logits_tile_supported(const GemvArgs &a);
 void launch_logits_tile(const GemvArgs &a, hipStream_t st);
 void launch_self_attn_wg(const float *q, const void *kcache, const void *vcache, const int *d_slot, const int *d_pos,
@@ -171,21 +222,12 @@ void launch_proj_wg(const GemvArgs &a, hipStream_t st);
 // ------------------------------------------------------------------------------------------
 // K9/K10 logits rules + samplers (logits.hip)
 // ------------------------------------------------------------------------------------------
-constexpr int MAX_CAND = 8;
-
 struct LogitsParams {
     int n_vocab, eot, beg, space_id;
     int suppress_blank;
     float temperature;
     int tid0_initial;  // round(max_initial_ts / 0.02), <0: rule disabled
     int n_samples;     // 0: greedy argmax ("best"); k>0: draw k samples from the distribution
-};
-struct LogitsRowState {   // per decoder row, uploaded per step
-    int logits_row;       // row of the logits matrix
-    int n_sampled;        // tokens sampled so far (0 => initial)
-    int last_is_ts, penult_is_ts;
-    int has_ts, seek_delta;
-    double u[MAX_CAND];   // uniform draws for the samplers
 };
 struct LogitsRowResult {
     int tid;

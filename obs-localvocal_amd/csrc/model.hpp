@@ -69,6 +69,8 @@ struct DecLayer {
     float *fc2_b;
 };
 
+struct Hub;  // engine.hpp: the per-GPU batcher of decode steps over the contexts that share these weights
+
 struct Model {
     HParams hp;
     Vocab vocab;
@@ -95,6 +97,8 @@ struct Model {
     // the device allocations (arena, mel tables) are reference-counted: a copy of a Model is a view of the same
     // HBM-resident weights (one upload per GPU, any number of stream contexts: mw_init_shared)
     std::shared_ptr<void> arena_owner, mel_tab_owner;
+    // contexts that share the weights also share the hub that batches their decode steps (null: no batched path)
+    std::shared_ptr<Hub> hub;
 };
 
 // Parses `size` bytes at `data` (a whole ggml-*.bin image) and uploads to the current HIP device.

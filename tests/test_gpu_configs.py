@@ -217,3 +217,116 @@ def test_tile_kernels_every_model_width_bf16(pkg, model_file, width, heads):
     finally:
         eng.close()
         orc.close()
+
+
+def test_batched_steps_across_streams_equal_solo_runs(pkg, model_file):
+    # Decode steps of contexts that share one weight upload are batched by the hub: rows of different streams ride in ONE
+    # weight pass (up to 16 rows / 16 requests per step).  12 streams on a 512-wide model (tile kernels), beam search (5 rows
+    # each, so a step holds up to 3 streams) and greedy, every stream with its own clip: tokens, segments and token
+    # probabilities equal to the stream's solo run, and the hub's counters show that steps really were shared.
+    import threading
+    path = model_file("tiny.en", ftype=1, n_audio_layer=2, n_text_layer=2, n_audio_state=512, n_audio_head=8,
+                      n_text_state=512, n_text_head=8)
+    n_streams, steps, rounds = 12, 20, 2
+    clips = [ggml_io.synth_pcm(400 + i, 6.0 + 0.5 * (i % 3)) for i in range(n_streams)]
+
+    def make():
+        first = pkg.Engine(path, precision=pkg.PRECISION_BF16)
+        engs = [first] + [pkg.Engine(path, precision=pkg.PRECISION_BF16, share=first) for _ in range(n_streams - 1)]
+        params = []
+        for i, e in enumerate(engs):
+            e.set_force_decode_steps(steps)
+            strategy = pkg.SAMPLING_BEAM_SEARCH if i % 2 == 0 else pkg.SAMPLING_GREEDY
+            params.append(e.default_params(strategy, temperature_inc=0.0, duration_ms=int(len(clips[i]) * 1000 // 16000),
+                                           language="en"))
+        return engs, params
+
+    # solo reference: fresh contexts, one stream at a time (beam search draws from the context's persistent mt19937, so the
+    # k-th call of a context is compared with the k-th call of a fresh context)
+    engs, params = make()
+    try:
+        assert engs[0].hub_stats() is not None
+        solo = []
+        for i, e in enumerate(engs):
+            rounds_i = []
+            for _ in range(rounds):
+                assert e.full(params[i], clips[i]) == 0
+                rounds_i.append(e.segments())
+            solo.append(rounds_i)
+        s0 = engs[0].hub_stats()
+        assert s0[1] >= s0[0] and s0[2] == s0[0]            # alone: one request per step
+    finally:
+        for e in engs[1:] + engs[:1]:
+            e.close()
+    engs, params = make()
+    try:
+        s0 = engs[0].hub_stats()
+        out, errs = [[] for _ in range(n_streams)], []
+        gate = threading.Barrier(n_streams)
+
+        def work(i):
+            try:
+                gate.wait()
+                for _ in range(rounds):
+                    assert engs[i].full(params[i], clips[i]) == 0
+                    out[i].append(engs[i].segments())
+            except Exception as ex:  # noqa: BLE001
+                errs.append(repr(ex))
+
+        th = [threading.Thread(target=work, args=(i,)) for i in range(n_streams)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, errs
+        for i in range(n_streams):
+            assert out[i] == solo[i], f"stream {i}"
+        s1 = engs[0].hub_stats()
+        d_steps, d_rows, d_req = (s1[k] - s0[k] for k in range(3))
+        print(f"hub: {d_req} requests in {d_steps} steps ({d_req / d_steps:.2f} requests, {d_rows / d_steps:.2f} rows per step)")
+        assert d_req > d_steps                               # requests of different streams shared steps
+    finally:
+        for e in engs[1:] + engs[:1]:
+            e.close()
+
+
+def test_mel_is_bit_exact_while_other_contexts_encode(pkg, model_file):
+    # Regression: built with hipcc's SLP vectoriser (packed-f32 VALU), mel_frames_kernel returned a few wrong values per call
+    # whenever kernels of OTHER contexts shared its compute units (alone it was bit-exact) — 150 of 240 calls differed.
+    # The library is built with -fno-slp-vectorize (csrc/Makefile); every call must equal the stream's solo result.
+    import threading
+    path = model_file("tiny.en", ftype=1, n_audio_layer=2, n_text_layer=2, n_audio_state=512, n_audio_head=8,
+                      n_text_state=512, n_text_head=8)
+    n = 8
+    clips = [ggml_io.synth_pcm(400 + i, 6.0 + 0.5 * (i % 3)) for i in range(n)]
+    first = pkg.Engine(path, precision=pkg.PRECISION_BF16)
+    engs = [first] + [pkg.Engine(path, precision=pkg.PRECISION_BF16, share=first) for _ in range(n - 1)]
+    try:
+        for i in range(n):
+            engs[i].mel(clips[i])
+            engs[i].encode(0)
+        solo = [engs[i].mel(clips[i]).copy() for i in range(4)]
+        stop, bad = [False], [0]
+
+        def noisy(i):
+            while not stop[0]:
+                engs[i].encode(0)
+
+        def checker(i):
+            for _ in range(25):
+                if not np.array_equal(engs[i].mel(clips[i]), solo[i]):
+                    bad[0] += 1
+
+        tn = [threading.Thread(target=noisy, args=(i,)) for i in range(4, n)]
+        tc = [threading.Thread(target=checker, args=(i,)) for i in range(4)]
+        for t in tn + tc:
+            t.start()
+        for t in tc:
+            t.join()
+        stop[0] = True
+        for t in tn:
+            t.join()
+        assert bad[0] == 0, f"{bad[0]} of 100 mel calls differ from the solo result"
+    finally:
+        for e in engs[1:] + engs[:1]:
+            e.close()
