@@ -100,10 +100,11 @@ int mw_synchronize(struct whisper_context *ctx);
    behaviour.  See DESIGN.md "forced decode length". */
 int mw_set_force_decode_steps(struct whisper_context *ctx, int n);
 /* Counters of the batcher that runs the decode steps of every context sharing ctx's weights on its GPU:
-   out = {batched steps run, activation rows in them, decode requests served}.  rows / steps > rows per request means
-   rows of different streams really shared weight passes.  Returns 1 (and zeros) when ctx does not use the batcher
+   out = {batched steps run, activation rows in them, decode requests served, encoder passes run, 30 s windows in them}.
+   rows / steps > rows per request means rows of different streams really shared weight passes; windows / passes > 1 the
+   same for the encoder.  Returns 1 (and zeros) when ctx does not use the batcher
    (fp32 mode, widths without tile kernels).  No counterpart in the reference. */
-int mw_hub_stats(struct whisper_context *ctx, unsigned long long out[3]);
+int mw_hub_stats(struct whisper_context *ctx, unsigned long long out[5]);
 /* Measurement-only: every launch of kernel class `step_class` (MW_STEP_*, -1: off) inside the replayed decode step is
    issued twice (the second writes a scratch output where the kernel updates in place), so that
    (time with - time without) / launches is the class's cost INSIDE graph replay; results are unchanged.  No

@@ -419,8 +419,9 @@ class Engine:
         self._check(self.L.mw_set_force_decode_steps(self.ctx, n), "mw_set_force_decode_steps")
 
     def hub_stats(self):
-        """(steps, rows, requests) of the batcher shared with the other contexts on these weights, or None."""
-        out = (C.c_ulonglong * 3)()
+        """(steps, rows, requests, encoder passes, encoder windows) of the batcher shared with the other contexts on
+        these weights, or None."""
+        out = (C.c_ulonglong * 5)()
         rc = self.L.mw_hub_stats(self.ctx, out)
         return None if rc != 0 else tuple(int(x) for x in out)
 

@@ -645,15 +645,18 @@ int mw_set_force_decode_steps(struct whisper_context *ctx, int n) {
     return 0;
 }
 
-int mw_hub_stats(struct whisper_context *ctx, unsigned long long out[3]) {
+int mw_hub_stats(struct whisper_context *ctx, unsigned long long out[5]) {
     if (!ctx || !ctx->c || !out) return -1;
-    out[0] = out[1] = out[2] = 0;
+    for (int i = 0; i < 5; ++i) out[i] = 0;
     Hub *h = ctx->c->model.hub.get();
     if (!h || !ctx->c->use_hub) return 1;  // this context runs its own steps (fp32 mode or a width without tile kernels)
     std::lock_guard<std::mutex> lk(h->mu);
     out[0] = h->n_steps;
     out[1] = h->n_rows;
     out[2] = h->n_requests;
+    std::lock_guard<std::mutex> lke(h->mu_enc);
+    out[3] = h->n_enc_passes;
+    out[4] = h->n_enc_windows;
     return 0;
 }
 

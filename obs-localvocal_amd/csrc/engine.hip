@@ -158,19 +158,29 @@ std::unique_ptr<Context> create_context_impl(const unsigned char *data, size_t s
 }  // namespace
 
 
+std::mutex g_capture_mu;  // see the capture sites
+
 // ------------------------------------------------------------------------------------------
 // the hub: one batched decode step over the rows of several contexts (engine.hpp)
 // ------------------------------------------------------------------------------------------
 Hub::~Hub() {
     (void)hipSetDevice(device);
-    if (st) (void)hipStreamSynchronize(st);
-    void *ptrs[] = {d_blk, d_x, d_q, d_part, d_logits, d_work, d_attd, d_ffd, d_head_cnt, d_suppress};
+    for (Lane &ln : lanes)
+        if (ln.st) (void)hipStreamSynchronize(ln.st);
+    if (st_enc) (void)hipStreamSynchronize(st_enc);
+    for (Lane &ln : lanes) {
+        void *ptrs[] = {ln.d_blk, ln.d_x, ln.d_q, ln.d_part, ln.d_logits, ln.d_work, ln.d_attd, ln.d_ffd, ln.d_head_cnt, ln.d_suppress};
+        for (void *p : ptrs)
+            if (p) (void)hipFree(p);
+        if (ln.h_blk) (void)hipHostFree(ln.h_blk);
+        if (ln.h_res) (void)hipHostFree(ln.h_res);
+        for (auto &kv : ln.graphs) (void)hipGraphExecDestroy(kv.second);
+        if (ln.st) (void)hipStreamDestroy(ln.st);
+    }
+    void *ptrs[] = {e_conv_in, e_x1, e_h, e_qk, e_vt, e_att, e_ff, e_x};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
-    if (h_blk) (void)hipHostFree(h_blk);
-    if (h_res) (void)hipHostFree(h_res);
-    for (auto &kv : graphs) (void)hipGraphExecDestroy(kv.second);
-    if (st) (void)hipStreamDestroy(st);
+    if (st_enc) (void)hipStreamDestroy(st_enc);
 }
 
 std::shared_ptr<Hub> create_hub(const Model &m, int device, bool use_graphs) {
@@ -183,36 +193,199 @@ std::shared_ptr<Hub> create_hub(const Model &m, int device, bool use_graphs) {
     h->use_graphs = use_graphs;
     const HParams &hp = m.hp;
     const size_t d = hp.n_text_state, H = hp.n_text_head, nv = hp.n_vocab, R = STEP_MAX_ROWS;
-    MW_HIP(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
-    MW_HIP(hipHostMalloc((void **)&h->h_blk, sizeof(StepBlock)));
-    memset(h->h_blk, 0, sizeof(StepBlock));
-    MW_HIP(hipHostGetDevicePointer((void **)&h->h_blk_dev, h->h_blk, 0));
-    MW_HIP(hipHostMalloc((void **)&h->h_res, R * sizeof(LogitsRowResult)));
-    MW_HIP(hipHostGetDevicePointer((void **)&h->h_res_dev, h->h_res, 0));
-    dev_alloc(h->d_blk, 1);
-    dev_alloc(h->d_x, R * d);
-    dev_alloc(h->d_q, R * d);
-    dev_alloc_bytes(h->d_attd, R * d * 2);
-    dev_alloc_bytes(h->d_ffd, R * 4 * d * 2);
-    dev_alloc(h->d_part, R * H * CROSS_SPLITS_MAX * 66);
-    dev_alloc(h->d_logits, R * nv);
-    dev_alloc(h->d_work, process_logits_work_floats((int)R, (int)nv));
-    dev_alloc(h->d_suppress, nv);
-    dev_alloc(h->d_head_cnt, (size_t)STEP_MAX_GROUPS * 64);
-    MW_HIP(hipMemsetAsync(h->d_head_cnt, 0, (size_t)STEP_MAX_GROUPS * 64 * sizeof(unsigned), h->st));
-    MW_HIP(hipStreamSynchronize(h->st));
+    // Plain streams on purpose.  High-priority lane streams (hipStreamCreateWithPriority) changed nothing with one or two
+    // lanes and collapsed throughput 30x with three or more (64 turbo streams: 4266 audio-s/s -> 151): HIP keeps a separate,
+    // smaller pool of hardware queues per priority class.
+    if (const char *e = getenv("MI355_WHISPER_LANES")) h->n_lanes = std::max(1, std::min(Hub::N_LANES, atoi(e)));
+    for (int li = 0; li < h->n_lanes; ++li) {
+        Hub::Lane &ln = h->lanes[li];
+        MW_HIP(hipStreamCreateWithFlags(&ln.st, hipStreamNonBlocking));
+        MW_HIP(hipHostMalloc((void **)&ln.h_blk, sizeof(StepBlock)));
+        memset(ln.h_blk, 0, sizeof(StepBlock));
+        MW_HIP(hipHostGetDevicePointer((void **)&ln.h_blk_dev, ln.h_blk, 0));
+        MW_HIP(hipHostMalloc((void **)&ln.h_res, R * sizeof(LogitsRowResult)));
+        MW_HIP(hipHostGetDevicePointer((void **)&ln.h_res_dev, ln.h_res, 0));
+        dev_alloc(ln.d_blk, 1);
+        dev_alloc(ln.d_x, R * d);
+        dev_alloc(ln.d_q, R * d);
+        dev_alloc_bytes(ln.d_attd, R * d * 2);
+        dev_alloc_bytes(ln.d_ffd, R * 4 * d * 2);
+        dev_alloc(ln.d_part, R * H * CROSS_SPLITS_MAX * 66);
+        dev_alloc(ln.d_logits, R * nv);
+        dev_alloc(ln.d_work, process_logits_work_floats((int)R, (int)nv));
+        dev_alloc(ln.d_suppress, nv);
+        dev_alloc(ln.d_head_cnt, (size_t)STEP_MAX_GROUPS * 64);
+        MW_HIP(hipMemsetAsync(ln.d_head_cnt, 0, (size_t)STEP_MAX_GROUPS * 64 * sizeof(unsigned), ln.st));
+    }
+    {   // encoder workspace for ENC_MAX_WINDOWS windows (slabs back to back)
+        const size_t W = Hub::ENC_MAX_WINDOWS, da = hp.n_audio_state, T = hp.n_audio_ctx, tp = (T + 63) / 64 * 64;
+        MW_HIP(hipStreamCreateWithFlags(&h->st_enc, hipStreamNonBlocking));
+        dev_alloc_bytes(h->e_conv_in, W * (2 * T + 2) * hp.n_mels * 2);
+        dev_alloc_bytes(h->e_x1, W * (2 * T + 1) * da * 2);
+        dev_alloc(h->e_x, W * T * da);
+        dev_alloc_bytes(h->e_h, W * T * da * 2);
+        dev_alloc_bytes(h->e_qk, W * T * 2 * da * 2);
+        dev_alloc_bytes(h->e_vt, W * da * tp * 2);
+        dev_alloc_bytes(h->e_att, W * T * da * 2);
+        dev_alloc_bytes(h->e_ff, W * T * 4 * da * 2);
+        MW_HIP(hipMemsetAsync(h->e_x1, 0, W * (2 * T + 1) * da * 2, h->st_enc));  // row 0 of every window is conv2's left zero pad
+        MW_HIP(hipMemsetAsync(h->e_vt, 0, W * da * tp * 2, h->st_enc));           // pad columns stay zero
+        MW_HIP(hipStreamSynchronize(h->st_enc));
+    }
+    for (int li = 0; li < h->n_lanes; ++li) MW_HIP(hipStreamSynchronize(h->lanes[li].st));
     return h;
 }
+
+void Hub::submit_encode(EncRequest &r) {
+    std::unique_lock<std::mutex> lk(mu_enc);
+    queue_enc.push_back(&r);
+    while (!r.done) {
+        if (busy_enc) {
+            cv_enc.wait(lk);
+            continue;
+        }
+        // idle: this thread leads the next pass over the oldest request and every later one with the same audio context
+        std::vector<EncRequest *> batch;
+        EncRequest *first = queue_enc.front();
+        for (auto it = queue_enc.begin(); it != queue_enc.end();) {
+            if ((int)batch.size() < ENC_MAX_WINDOWS && (*it)->n_ctx == first->n_ctx) {
+                batch.push_back(*it);
+                it = queue_enc.erase(it);
+            } else {
+                ++it;
+            }
+        }
+        busy_enc = true;
+        lk.unlock();
+        std::exception_ptr err;
+        try {
+            run_encode(batch);
+        } catch (...) {
+            err = std::current_exception();
+            (void)hipStreamSynchronize(st_enc);
+        }
+        lk.lock();
+        for (EncRequest *q : batch) {
+            q->err = err;
+            q->done = true;
+        }
+        n_enc_passes += 1;
+        n_enc_windows += batch.size();
+        busy_enc = false;
+        cv_enc.notify_all();
+    }
+    lk.unlock();
+    if (r.err) std::rethrow_exception(r.err);
+}
+
+// Encoder + cross-K/V (A.3) of W windows in one pass: the conv stem and the attention are batched over the windows, every
+// projection and LayerNorm of the transformer blocks runs over all W x n_ctx rows at once.
+void Hub::run_encode(const std::vector<EncRequest *> &batch) {
+    MW_HIP(hipSetDevice(device));
+    const HParams &hp = m.hp;
+    const DType wt = DType::BF16;
+    const size_t ws = 2;
+    const int W = (int)batch.size(), n_ctx = batch[0]->n_ctx;
+    const int d = hp.n_audio_state, H = hp.n_audio_head, n_mel = hp.n_mels, T2 = 2 * n_ctx;
+    const int tp = (n_ctx + 63) / 64 * 64;
+    hipStream_t s = st_enc;
+    const long cin_w = (long)(T2 + 2) * n_mel, x1_w = (long)(T2 + 1) * d;  // per-window slab sizes (elements)
+    for (int w = 0; w < W; ++w) {
+        Context &c = *batch[w]->c;
+        MW_CHECK(c.model.arena == m.arena && c.d_mel != nullptr, "hub: encode request of a foreign context / no mel");
+        if (c.st_dirty) {  // the window's mel is still being produced on the context's own stream
+            MW_HIP(hipStreamWaitEvent(s, c.ev_ready, 0));
+            c.st_dirty = false;
+        }
+        launch_mel_window(c.d_mel, 0, c.n_len, batch[w]->seek, T2, n_mel, 1, (char *)e_conv_in + (size_t)w * cin_w * ws, cin_w, wt, s);
+    }
+    {   // conv1 over the overlapping row view of every window: output row t <- padded rows t, t+1, t+2
+        GemmArgs g;
+        g.A = e_conv_in; g.lda = n_mel; g.W = m.conv1_w; g.ldw = 3 * n_mel;
+        g.C = (char *)e_x1 + (size_t)d * ws; g.ldc = d;  // row 0 of every window stays zero (conv2's left pad)
+        g.bias = m.conv1_b; g.M = T2; g.N = d; g.K = 3 * n_mel; g.act = ACT_GELU;
+        g.nz0 = W; g.sA0 = cin_w; g.sC0 = x1_w;
+        launch_gemm(g, wt, wt, s);
+    }
+    {   // conv2, stride 2: output row t <- padded x1 rows 2t, 2t+1, 2t+2; + positional embedding
+        GemmArgs g;
+        g.A = e_x1; g.lda = 2 * d; g.W = m.conv2_w; g.ldw = 3 * d;
+        g.C = e_x; g.ldc = d; g.bias = m.conv2_b; g.M = n_ctx; g.N = d; g.K = 3 * d; g.act = ACT_GELU;
+        g.R = m.enc_pe; g.ldr = d;
+        g.nz0 = W; g.sA0 = x1_w; g.sC0 = (long)n_ctx * d; g.sR0 = 0;
+        launch_gemm(g, wt, DType::F32, s);
+    }
+    const int M = W * n_ctx;
+    for (int l = 0; l < hp.n_audio_layer; ++l) {
+        const EncLayer &e = m.enc[l];
+        launch_layernorm(e_x, d, e.ln1_w, e.ln1_b, e_h, d, wt, M, d, s);
+        {
+            GemmArgs g;  // Q | K of all windows
+            g.A = e_h; g.lda = d; g.W = e.qk_w; g.ldw = d; g.C = e_qk; g.ldc = 2 * d; g.bias = e.qk_b;
+            g.M = M; g.N = 2 * d; g.K = d;
+            launch_gemm(g, wt, wt, s);
+        }
+        {
+            GemmArgs g;  // V, stored transposed [d][tp] per window
+            g.A = e_h; g.lda = d; g.W = e.v_w; g.ldw = d; g.C = e_vt; g.ldc = tp; g.bias = e.v_b;
+            g.M = n_ctx; g.N = d; g.K = d; g.trans_c = 1;
+            g.nz0 = W; g.sA0 = (long)n_ctx * d; g.sC0 = (long)d * tp;
+            launch_gemm(g, wt, wt, s);
+        }
+        launch_enc_flash_attn(e_qk, e_vt, e_att, n_ctx, tp, d, H, s, W);
+        {
+            GemmArgs g;  // x += att Wo^T + bo
+            g.A = e_att; g.lda = d; g.W = e.out_w; g.ldw = d; g.C = e_x; g.ldc = d; g.bias = e.out_b;
+            g.R = e_x; g.ldr = d; g.M = M; g.N = d; g.K = d;
+            launch_gemm(g, wt, DType::F32, s);
+        }
+        launch_layernorm(e_x, d, e.ln2_w, e.ln2_b, e_h, d, wt, M, d, s);
+        {
+            GemmArgs g;
+            g.A = e_h; g.lda = d; g.W = e.fc1_w; g.ldw = d; g.C = e_ff; g.ldc = 4 * d; g.bias = e.fc1_b;
+            g.M = M; g.N = 4 * d; g.K = d; g.act = ACT_GELU;
+            launch_gemm(g, wt, wt, s);
+        }
+        {
+            GemmArgs g;
+            g.A = e_ff; g.lda = 4 * d; g.W = e.fc2_w; g.ldw = 4 * d; g.C = e_x; g.ldc = d; g.bias = e.fc2_b;
+            g.R = e_x; g.ldr = d; g.M = M; g.N = d; g.K = 4 * d;
+            launch_gemm(g, wt, DType::F32, s);
+        }
+    }
+    const int L = hp.n_text_layer;
+    const long per_layer = 2L * hp.n_audio_ctx * d;
+    for (int w = 0; w < W; ++w) {  // ln_post and the cross K / V of every decoder layer, into the window's own context
+        Context &c = *batch[w]->c;
+        launch_layernorm(e_x + (size_t)w * n_ctx * d, d, m.ln_post_w, m.ln_post_b, c.d_enc_out, d, wt, n_ctx, d, s);
+        GemmArgs g;
+        g.A = c.d_enc_out; g.lda = d; g.W = m.ckv_w; g.ldw = d; g.C = c.d_cross; g.ldc = d;
+        g.M = n_ctx; g.N = d; g.K = d; g.nz1 = L; g.sW1 = 2L * d * d; g.sC1 = per_layer;
+        g.alpha = powf(64.0f, -0.25f);
+        launch_gemm(g, wt, wt, s);
+        GemmArgs v = g;
+        v.W = (char *)m.ckv_w + (size_t)d * d * ws;
+        v.C = (char *)c.d_cross + (size_t)hp.n_audio_ctx * d * ws;
+        v.bias = m.ckv_b + d; v.sB1 = 2L * d; v.alpha = 1.0f;
+        launch_gemm(v, wt, wt, s);
+        c.n_ctx_cur = n_ctx;
+    }
+    MW_HIP(hipStreamSynchronize(s));
+}
+
 
 void Hub::submit(StepRequest &r) {
     std::unique_lock<std::mutex> lk(mu);
     queue.push_back(&r);
     while (!r.done) {
-        if (busy) {
+        Lane *lane = nullptr;
+        for (int li = 0; li < n_lanes && !lane; ++li)
+            if (!lanes[li].busy) lane = &lanes[li];
+        if (!lane || r.taken) {  // every lane is busy, or this request is already part of a running step
             cv.wait(lk);
             continue;
         }
-        // the hub is idle: this thread leads the next step.  It takes the oldest request and every later one that can
+        // a lane is idle: this thread leads the next step on it.  It takes the oldest request and every later one that can
         // share its step (same rules, rows / groups / logits rows / sampler rows within the step's limits), in order.
         std::vector<StepRequest *> batch;
         int rows = 0, lrows = 0, srows = 0;
@@ -225,6 +398,7 @@ void Hub::submit(StepRequest &r) {
                                                 lrows + q->n_logit_rows <= STEP_MAX_ROWS && srows + sr <= STEP_MAX_ROWS);
             if (fits) {
                 batch.push_back(q);
+                q->taken = true;
                 rows += q->n;
                 lrows += q->n_logit_rows;
                 srows += sr;
@@ -233,14 +407,14 @@ void Hub::submit(StepRequest &r) {
                 ++it;
             }
         }
-        busy = true;
+        lane->busy = true;
         lk.unlock();
         std::exception_ptr err;
         try {
-            run(batch);
+            run(*lane, batch);
         } catch (...) {
             err = std::current_exception();
-            (void)hipStreamSynchronize(st);  // nothing of the failed step may still be running when its requests return
+            (void)hipStreamSynchronize(lane->st);  // nothing of the failed step may still be running when its requests return
         }
         lk.lock();
         for (StepRequest *q : batch) {
@@ -250,15 +424,25 @@ void Hub::submit(StepRequest &r) {
         n_steps += 1;
         n_rows += (unsigned long long)rows;
         n_requests += batch.size();
-        busy = false;
+        lane->busy = false;
         cv.notify_all();
     }
     lk.unlock();
     if (r.err) std::rethrow_exception(r.err);
 }
 
-void Hub::run(const std::vector<StepRequest *> &batch) {
+void Hub::run(Lane &ln, const std::vector<StepRequest *> &batch) {
     MW_HIP(hipSetDevice(device));
+    hipStream_t st = ln.st;
+    StepBlock *const h_blk = ln.h_blk, *const h_blk_dev = ln.h_blk_dev, *const d_blk = ln.d_blk;
+    float *const d_x = ln.d_x, *const d_q = ln.d_q, *const d_part = ln.d_part, *const d_logits = ln.d_logits, *const d_work = ln.d_work;
+    void *const d_attd = ln.d_attd, *const d_ffd = ln.d_ffd;
+    unsigned *const d_head_cnt = ln.d_head_cnt;
+    LogitsRowResult *const h_res = ln.h_res, *const h_res_dev = ln.h_res_dev;
+    unsigned char *const d_suppress = ln.d_suppress;
+    std::string &suppress_key = ln.suppress_key;
+    auto &graphs = ln.graphs;
+    auto &graph_lru = ln.graph_lru;
     const HParams &hp = m.hp;
     const int d = hp.n_text_state, H = hp.n_text_head, TC = hp.n_text_ctx, T = hp.n_audio_ctx, nv = hp.n_vocab;
     StepBlock &B = *h_blk;
@@ -425,6 +609,9 @@ void Hub::run(const std::vector<StepRequest *> &batch) {
                 }
             }
             hipGraph_t graph = nullptr;
+            // one capture (and instantiation) at a time in the process: a precaution, lanes and contexts capture from several
+            // threads and a capture is rare (once per step shape); replays of finished graphs run concurrently
+            std::lock_guard<std::mutex> capture_lock(g_capture_mu);
             MW_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
             try {
                 enqueue();
@@ -512,12 +699,24 @@ void encode(Context &c, int seek) {
     const int tp = (n_ctx + 63) / 64 * 64;
     hipStream_t st = c.st;
     const double t0 = now_ms();
+    MW_CHECK(c.d_mel != nullptr, "encode called before any mel was computed");
+    if (wt == DType::BF16 && c.use_hub && c.model.hub && c.flash_attn && !c.gemm_glds) {
+        // batched path: the window joins the encoder pass of the hub (with the windows other contexts have queued)
+        EncRequest r;
+        r.c = &c;
+        r.seek = seek;
+        r.n_ctx = n_ctx;
+        if (c.st_dirty) MW_HIP(hipEventRecord(c.ev_ready, c.st));
+        c.model.hub->submit_encode(r);
+        c.tm.n_encode++;
+        c.tm.encode_ms += now_ms() - t0;
+        return;
+    }
     c.n_ctx_cur = n_ctx;
     auto gemm = [&](GemmArgs &g, DType in, DType out, hipStream_t s) {
         g.glds = c.gemm_glds ? 1 : 0;
         launch_gemm(g, in, out, s);
     };
-    MW_CHECK(c.d_mel != nullptr, "encode called before any mel was computed");
     launch_mel_window(c.d_mel, 0, c.n_len, seek, T2, n_mel, 1, c.d_conv_in, (long)(T2 + 2) * n_mel, wt, st);
     {   // conv1 as a GEMM over the overlapping row view: output row t <- padded rows t, t+1, t+2
         GemmArgs g;
@@ -857,6 +1056,9 @@ void decode(Context &c, const int *tokens, const int *pos, const int *slot, int 
                 }
             }
             hipGraph_t graph = nullptr;
+            // one capture (and instantiation) at a time in the process: a precaution, lanes and contexts capture from several
+            // threads and a capture is rare (once per step shape); replays of finished graphs run concurrently
+            std::lock_guard<std::mutex> capture_lock(g_capture_mu);
             MW_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
             try {
                 enqueue();

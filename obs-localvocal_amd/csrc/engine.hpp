@@ -59,6 +59,15 @@ struct StepRequest {
     bool keep_logits = false;  // copy the request's logits rows into c->d_logits (stage calls, language detection, unfused sampler)
     bool solo = false;         // measurement hooks armed on the context: never batched with other requests
     std::string rules_key;     // requests share a step only when their rules + sampler parameters are identical
+    bool taken = false;        // part of a step that is running on some lane
+    bool done = false;
+    std::exception_ptr err;
+};
+
+// One encoder pass (a 30 s window starting at mel frame `seek`) of one context, as the hub sees it.
+struct EncRequest {
+    Context *c = nullptr;
+    int seek = 0, n_ctx = 0;
     bool done = false;
     std::exception_ptr err;
 };
@@ -70,31 +79,54 @@ struct StepRequest {
 // rows), runs ONE step over all their rows — one pass over the weights — and hands every request its rows' results.
 // Requests that arrive while a step runs form the next step (no timed waiting: one stream alone is never delayed).
 struct Hub {
+    // One lane = a stream with the workspace and the captured graphs of one batched step.  Steps are latency-bound (eight
+    // dependent kernels per layer, each far from filling the chip), so several lanes run their steps side by side: a
+    // request that arrives while a lane is busy leads the next step on an idle lane instead of waiting.  One stream alone
+    // only ever uses lane 0.  Two lanes: measured on 64 turbo streams 4018 audio-s/s with one, 4465 with two, 4266 with four
+    // (the box gives a process 4 hardware queues; lanes + encoder stream + the contexts' own streams share them).
+    static constexpr int N_LANES = 2;
+    struct Lane {
+        hipStream_t st = nullptr;
+        // step block: pinned host copy (and its device view) + the device copy the kernels read
+        StepBlock *h_blk = nullptr, *h_blk_dev = nullptr, *d_blk = nullptr;
+        float *d_x = nullptr, *d_q = nullptr, *d_part = nullptr, *d_logits = nullptr, *d_work = nullptr;
+        void *d_attd = nullptr, *d_ffd = nullptr;
+        unsigned *d_head_cnt = nullptr;
+        LogitsRowResult *h_res = nullptr, *h_res_dev = nullptr;  // pinned: the sampler stores its results straight into it
+        unsigned char *d_suppress = nullptr;  // the suppression mask of the lane's last rules (copied from the leader when the key changes)
+        std::string suppress_key;
+        std::unordered_map<uint64_t, hipGraphExec_t> graphs;
+        std::vector<uint64_t> graph_lru;
+        bool busy = false;
+    };
     int device = 0;
-    hipStream_t st = nullptr;
     Model m;  // non-owning view of the weights (owners reset: the hub is owned BY the models that point to it)
-    // step block: pinned host copy (and its device view) + the device copy the kernels read
-    StepBlock *h_blk = nullptr, *h_blk_dev = nullptr, *d_blk = nullptr;
-    float *d_x = nullptr, *d_q = nullptr, *d_part = nullptr, *d_logits = nullptr, *d_work = nullptr;
-    void *d_attd = nullptr, *d_ffd = nullptr;
-    unsigned *d_head_cnt = nullptr;
-    LogitsRowResult *h_res = nullptr, *h_res_dev = nullptr;  // pinned: the sampler stores its results straight into it
-    unsigned char *d_suppress = nullptr;  // the suppression mask of the last step's rules (copied from its leader when the key changes)
-    std::string suppress_key;
+    Lane lanes[N_LANES];
+    int n_lanes = N_LANES;  // lanes in use (MI355_WHISPER_LANES, read when the hub is created)
     bool use_graphs = true;
-    std::unordered_map<uint64_t, hipGraphExec_t> graphs;
-    std::vector<uint64_t> graph_lru;
     std::mutex mu;
     std::condition_variable cv;
     std::deque<StepRequest *> queue;
-    bool busy = false;
     // statistics (mw_hub_stats)
-    unsigned long long n_steps = 0, n_rows = 0, n_requests = 0;
+    unsigned long long n_steps = 0, n_rows = 0, n_requests = 0, n_enc_passes = 0, n_enc_windows = 0;
+    // encoder passes of the same contexts, batched the same way on a stream of their own: the windows of up to
+    // ENC_MAX_WINDOWS streams run as ONE pass with M = windows x n_ctx rows in every projection (more tiles per launch,
+    // one pass over the encoder weights); each window's cross K / V goes to its own context
+    static constexpr int ENC_MAX_WINDOWS = 8;
+    hipStream_t st_enc = nullptr;
+    void *e_conv_in = nullptr, *e_x1 = nullptr, *e_h = nullptr, *e_qk = nullptr, *e_vt = nullptr, *e_att = nullptr, *e_ff = nullptr;
+    float *e_x = nullptr;
+    std::mutex mu_enc;
+    std::condition_variable cv_enc;
+    std::deque<EncRequest *> queue_enc;
+    bool busy_enc = false;
 
     ~Hub();
     void submit(StepRequest &r);  // blocks until the request's step has run; rethrows its error
+    void submit_encode(EncRequest &r);  // blocks until the window is encoded and its cross K / V are in the context
   private:
-    void run(const std::vector<StepRequest *> &batch);
+    void run(Lane &ln, const std::vector<StepRequest *> &batch);
+    void run_encode(const std::vector<EncRequest *> &batch);
 };
 std::shared_ptr<Hub> create_hub(const Model &m, int device, bool use_graphs);
 

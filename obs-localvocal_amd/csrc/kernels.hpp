@@ -81,7 +81,9 @@ void launch_layernorm(const float *x, long ldx, const float *w, const float *b, 
 // rows x n scaled softmax of f32 scores, written as out_t with columns [n, n_pad) zeroed
 // fused encoder self-attention, bf16: qk = [n_ctx][2d] (Q | K), vt = V transposed [d][tp] (pad columns finite),
 // out = [n_ctx][d]; heads of 64
-void launch_enc_flash_attn(const void *qk, const void *vt, void *out, int n_ctx, int tp, int d, int H, hipStream_t st);
+// n_windows > 1: the windows of a batched encoder pass, slabs back to back (qk [w][n_ctx][2d], vt [w][d][tp], out [w][n_ctx][d])
+void launch_enc_flash_attn(const void *qk, const void *vt, void *out, int n_ctx, int tp, int d, int H, hipStream_t st,
+                           int n_windows = 1);
 void launch_softmax_rows(const float *s, long lds_, void *out, long ldo, DType out_t, long rows, int n, int n_pad,
                          float scale, hipStream_t st);
 void launch_fill_zero(void *p, size_t bytes, hipStream_t st);

@@ -285,6 +285,9 @@ def test_batched_steps_across_streams_equal_solo_runs(pkg, model_file):
         d_steps, d_rows, d_req = (s1[k] - s0[k] for k in range(3))
         print(f"hub: {d_req} requests in {d_steps} steps ({d_req / d_steps:.2f} requests, {d_rows / d_steps:.2f} rows per step)")
         assert d_req > d_steps                               # requests of different streams shared steps
+        d_pass, d_win = s1[3] - s0[3], s1[4] - s0[4]
+        print(f"hub: {d_win} encoder windows in {d_pass} passes")
+        assert d_win >= n_streams * rounds and d_pass < d_win  # ... and windows of different streams shared encoder passes
     finally:
         for e in engs[1:] + engs[:1]:
             e.close()
