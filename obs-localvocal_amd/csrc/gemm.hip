@@ -38,6 +38,15 @@ __device__ __forceinline__ float gelu_f(float x) {
     return 0.5f * x * (1.0f + tanhf(c * x * (1.0f + a * x * x)));
 }
 
+// bf16 paths: the same function as x * sigmoid(2u), u = c x (1 + a x^2), on the hardware exp2 and reciprocal (a handful of
+// instructions instead of tanhf's ~40; fc1's epilogue at M = 12000 cost 55 us of 300 with tanhf).  Relative error ~1e-6,
+// far below the bf16 rounding of the result; the fp32 (token-exact) kernel keeps tanhf.
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float c2 = 2.0f * 0.79788456080286535587989211986876f, a = 0.044715f;
+    const float u2 = c2 * x * fmaf(a * x, x, 1.0f);
+    return __fdividef(x, 1.0f + __expf(-u2));
+}
+
 __device__ __forceinline__ void store_out(float *p, float v) { *p = v; }
 __device__ __forceinline__ void store_out(bf16_t *p, float v) {
     __hip_bfloat16 h = __float2bfloat16(v);
@@ -258,7 +267,7 @@ __device__ __forceinline__ void gemm_bf16_epilogue(const GemmArgs &a, f32x4 (&ac
                 const int m = TR ? mb + r : mb, n = TR ? nb : nb + r;
                 float x = acc[i][j][r] * a.alpha;
                 if (bias) x += bias[min(n, N - 1)];
-                if (a.act == ACT_GELU) x = gelu_f(x);
+                if (a.act == ACT_GELU) x = gelu_fast(x);
                 if (R) x += R[(long)min(m, M - 1) * a.ldr + min(n, N - 1)];
                 v[r] = x;
             }
@@ -416,9 +425,16 @@ __global__ __launch_bounds__(256) void gemm_bf16_k64_kernel(GemmArgs a) {
 // wave's counted `s_waitcnt vmcnt` (the DMAs of the two younger steps stay in flight) followed by that barrier — one
 // barrier per k-step, a raw s_barrier (__syncthreads() would drain the DMAs).  Steps beyond the last reload the last
 // tile into a free stage so that the count is the same in every iteration.  Needs K % 64 == 0 (no zero-fill of a tail).
-template <typename TOUT, int BM, bool TR>
-__global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(GemmArgs a) {
-    constexpr int BK = 64, RB = 128, TILE_A = BM * RB, TILE_W = 128 * RB, STAGE = TILE_A + TILE_W, GS = 4;
+//
+// GS = 1 is the kernel of the many-tile grids (encoder pass over the windows of several streams, M = windows x 1500): one
+// 32 KB stage, two barriers per k-step, registers capped at 128 — FOUR workgroups per CU, which cover each other's load
+// latency and, above all, each other's prologue and epilogue: with one or two workgroups per CU every CU runs its tiles in
+// lockstep (all load, then all multiply, then all store) and a K = 1280 tile spent 15 of its 33 us outside the k-loop.
+// Measured at M = 12000 (tools/microbench/mb_gemm): Q|K 143 -> 106 us (739 TFLOP/s), fc1 324 -> 222, fc2 237 -> 196,
+// attention output 102 -> 79 against the register-ring kernel; 256 x 128 tiles and 2- or 3-stage rings measured no better.
+template <typename TOUT, int BM, bool TR, int GS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GS == 1 ? 4 : 1, GS == 1 ? 4 : 2))) void gemm_bf16_glds_kernel(GemmArgs a) {
+    constexpr int BK = 64, RB = 128, TILE_A = BM * RB, TILE_W = 128 * RB, STAGE = TILE_A + TILE_W;
     constexpr int WJ = BM == 128 ? 4 : 2, WCOLS = BM == 128 ? 64 : 32, QA = BM == 128 ? 4 : 2, LPS = QA + 4;
     __shared__ __attribute__((aligned(1024))) unsigned char lds[GS * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -462,11 +478,24 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(GemmArgs a) {
     for (int u = 0; u < GS - 1; ++u) issue(u, u);
     const int fr = lane & 15, fq = lane >> 4;
     for (int kt = 0; kt < nk; ++kt) {
+        if constexpr (GS == 1) {
+            // one stage, two barriers per k-step: the latency of a step's loads is covered by the other workgroups of the CU
+            // (32 KB of LDS and <= 128 registers: four of them)
+            if (kt > 0) __builtin_amdgcn_s_barrier();  // every wave has read step kt - 1
+            issue(kt, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        } else {
         // this wave's DMAs of step kt are done when at most the 2 * LPS younger ones are outstanding ...
-        if constexpr (LPS == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        static_assert(GS >= 1 && GS <= 4, "stages");
+        if constexpr ((GS - 2) * LPS == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if constexpr ((GS - 2) * LPS == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if constexpr ((GS - 2) * LPS == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if constexpr ((GS - 2) * LPS == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // ... and every wave's are, behind the barrier; stage (kt - 1) % GS is free again
         issue(kt + GS - 1, (kt + GS - 1) % GS);
+        }
         const unsigned char *la = lds + (kt % GS) * STAGE, *lw = la + TILE_A;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -507,7 +536,11 @@ void launch_gemm(const GemmArgs &args, DType in, DType out, hipStream_t st) {
     // Q|K (240 tiles of 128 rows) 29.6 us, as 480 tiles of 64 rows 26.4; fc1 (480 tiles): 48 vs 56
     const long tiles128 = (long)ceil_div(a.N, BN) * ceil_div(a.M, 128) * a.nz0 * a.nz1;
     const bool bm64 = in == DType::BF16 && tiles128 < 300 && a.M > 64;
-    dim3 grid(ceil_div(a.N, BN), ceil_div(a.M, bm64 ? 64 : 128), a.nz0 * a.nz1);
+    // many-tile grids (the encoder pass over the windows of several streams, M = windows x 1500): the single-stage LDS-direct
+    // kernel, four workgroups per CU
+    const bool many = in == DType::BF16 && !a.trans_c && a.K % 64 == 0 && a.K >= 256 && tiles128 >= 900;
+    const int bm = bm64 ? 64 : 128;
+    dim3 grid(ceil_div(a.N, BN), ceil_div(a.M, bm), a.nz0 * a.nz1);
     MW_CHECK(grid.y <= 65535, "gemm: M too large for grid.y");
     {   // XCD-aware tile order (xcd_tile_coord): super-row height for which an XCD's share of the tiles is a compact rectangle
         const long T = (long)grid.x * grid.y, G = T * grid.z, share = (G + 7) / 8;
@@ -517,7 +550,7 @@ void launch_gemm(const GemmArgs &args, DType in, DType out, hipStream_t st) {
                 a.hb = (int)grid.y;  // an XCD gets whole batch slices: any order inside a slice
             } else {
                 // rectangle of `share` tiles with equal operand bytes on both sides: h * BM = w * BN  ->  h = sqrt(share * BN / BM)
-                const double h = sqrt((double)share * BN / (bm64 ? 64 : 128));
+                const double h = sqrt((double)share * BN / bm);
                 double best = 1e30;
                 for (int xm = 1; xm <= 8; xm *= 2) {
                     const int hb = ceil_div((int)grid.y, xm);
@@ -540,10 +573,14 @@ void launch_gemm(const GemmArgs &args, DType in, DType out, hipStream_t st) {
     const bool glds = a.glds && in == DType::BF16 && a.K % 64 == 0 && a.K >= 256;
 #define GLDS_LAUNCH(TOv, BMv)                                                                                           \
     do {                                                                                                                \
-        if (a.trans_c) hipLaunchKernelGGL((gemm_bf16_glds_kernel<TOv, BMv, true>), grid, dim3(256), 0, st, a);          \
-        else hipLaunchKernelGGL((gemm_bf16_glds_kernel<TOv, BMv, false>), grid, dim3(256), 0, st, a);                   \
+        if (a.trans_c) hipLaunchKernelGGL((gemm_bf16_glds_kernel<TOv, BMv, true, 4>), grid, dim3(256), 0, st, a);       \
+        else hipLaunchKernelGGL((gemm_bf16_glds_kernel<TOv, BMv, false, 4>), grid, dim3(256), 0, st, a);                \
     } while (0)
-    if (in == DType::F32 && out == DType::F32)
+    if (many && out == DType::F32) {
+        hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, 128, false, 1>), grid, dim3(256), 0, st, a);
+    } else if (many) {
+        hipLaunchKernelGGL((gemm_bf16_glds_kernel<bf16_t, 128, false, 1>), grid, dim3(256), 0, st, a);
+    } else if (in == DType::F32 && out == DType::F32)
         hipLaunchKernelGGL((gemm_nt_kernel<float, float, 128>), grid, dim3(256), 0, st, a);
     else if (glds && out == DType::F32 && bm64)
         GLDS_LAUNCH(float, 64);

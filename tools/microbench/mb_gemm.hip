@@ -11,9 +11,11 @@ using namespace mw;
 int main(int argc, char **argv) {
     const int variant = argc > 1 ? atoi(argv[1]) : 0;
     const int d = 1280;
-    struct Shape { const char *name; int N, K; bool f32out, gelu, res; };
+    struct Shape { const char *name; int N, K; bool f32out, gelu, res; int probe = 0; };
     const Shape shapes[] = {{"qk", 2 * d, d, false, false, false}, {"out", d, d, true, false, true},
-                            {"fc1", 4 * d, d, false, true, false}, {"fc2", d, 4 * d, true, false, true}};
+                            {"fc1", 4 * d, d, false, true, false}, {"fc2", d, 4 * d, true, false, true},
+                            {"fc1n", 4 * d, d, false, false, false}, {"outn", d, d, true, false, false},
+                            {"outb", d, d, false, false, false}, {"fc2b", d, 4 * d, false, false, false}};
     const int Ws[] = {1, 4, 8};
     const size_t maxM = 8 * 1500;
     void *A, *Wt, *C; float *bias;
@@ -30,7 +32,7 @@ int main(int argc, char **argv) {
         for (const Shape &s : shapes) {
             GemmArgs g;
             g.A = A; g.lda = s.K; g.W = Wt; g.ldw = s.K; g.C = C; g.ldc = s.N; g.bias = bias;
-            g.M = W * 1500; g.N = s.N; g.K = s.K; g.act = s.gelu ? ACT_GELU : ACT_NONE;
+            g.M = W * 1500; g.N = s.N; g.K = s.K; g.act = s.probe ? s.probe : s.gelu ? ACT_GELU : ACT_NONE;
             if (s.res) { g.R = (float *)C; g.ldr = s.N; }
             g.glds = variant;
             const int it = 20;
@@ -41,7 +43,7 @@ int main(int argc, char **argv) {
             MW_HIP(hipEventSynchronize(e1));
             float ms; MW_HIP(hipEventElapsedTime(&ms, e0, e1));
             const double us = ms * 1e3 / it, tf = 2.0 * g.M * s.N * s.K / (us * 1e-6) / 1e12;
-            printf("W=%d %-4s M=%5d N=%4d K=%4d  %8.1f us  %7.1f TFLOP/s\n", W, s.name, g.M, s.N, s.K, us, tf);
+            printf("W=%d %-10s M=%5d N=%4d K=%4d  %8.1f us  %7.1f TFLOP/s\n", W, s.name, g.M, s.N, s.K, us, tf);
         }
     return 0;
 }
