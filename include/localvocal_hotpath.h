@@ -128,6 +128,20 @@ void lv_filter_reset_vad_state(lv_filter *f);
    thread running whisper_loop (whisper-processing.cpp:361-431).  0 on success. */
 int lv_filter_start(lv_filter *f, const char *model_path);
 void lv_filter_stop(lv_filter *f);
+/* update_whisper_model (whisper-model-utils.cpp:12-142): reads "whisper_model_path", "whisper_model_path_external" and
+   "dtw_token_timestamps" from the filter's settings (lv_settings_set_*) and switches the model + worker exactly as the
+   reference does: same name -> nothing; another name -> shutdown_whisper_thread (context freed under the context mutex,
+   parked worker woken and joined) then start with the catalogue's file; "!!!external!!!" -> the external file, unless that
+   file is the one loaded; a changed DTW flag -> the reference's restart with the path it has just cleared (fails; the
+   next call reloads).  Returns 0 when a context is loaded afterwards, 1 when the filter is left stopped, < 0 on errors. */
+int lv_filter_update_model(lv_filter *f);
+/* the catalogue update_whisper_model looks names up in (models_info() + find_model_bin_file, model-downloader.h):
+   name -> file on disk; file NULL or "" = listed but not downloaded (the download dialog is outside this library) */
+int lv_filter_register_model(lv_filter *f, const char *name, const char *file);
+/* gf->whisper_model_path, gf->whisper_model_file_currently_loaded, gf->whisper_model_loaded_new, whisper_thread.joinable(),
+   gf->enable_token_ts_dtw — for lifecycle tests and harnesses; any pointer may be NULL */
+int lv_filter_model_state(lv_filter *f, char *model_path, size_t n_path, char *file_loaded, size_t n_file, int *loaded_new,
+                          int *worker_running, int *dtw);
 
 /* VadIterator::process + get_speech_timestamps (silero-vad-onnx.cpp:262-309) on a standalone iterator
    with the filter's gate: writes up to cap (start,end) sample pairs, returns the count. */

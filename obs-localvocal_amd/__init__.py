@@ -114,7 +114,8 @@ EXPORTED_SYMBOLS = [
     "lv_filter_set_max_sub_duration", "lv_filter_enable_audio_chunks_callback", "lv_filter_set_vad_gate",
     "lv_filter_set_callbacks", "lv_filter_filter_audio", "lv_filter_push_packet", "lv_filter_clear_buffers",
     "lv_filter_input_bytes", "lv_filter_whisper_bytes", "lv_filter_segmentation_step", "lv_filter_reset_vad_state",
-    "lv_filter_start", "lv_filter_stop", "lv_vad_speech_timestamps", "lv_remove_leading_trailing_nonalpha",
+    "lv_filter_start", "lv_filter_stop", "lv_filter_update_model", "lv_filter_register_model", "lv_filter_model_state",
+    "lv_vad_speech_timestamps", "lv_remove_leading_trailing_nonalpha",
     "lv_resample",
 ]
 
@@ -260,6 +261,10 @@ def lib():
     L.lv_filter_reset_vad_state.argtypes = [P]
     L.lv_filter_start.argtypes = [P, C.c_char_p]
     L.lv_filter_stop.argtypes = [P]
+    L.lv_filter_update_model.argtypes = [P]
+    L.lv_filter_register_model.argtypes = [P, C.c_char_p, C.c_char_p]
+    L.lv_filter_model_state.argtypes = [P, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                        C.POINTER(C.c_int)]
     L.lv_vad_speech_timestamps.argtypes = [P, FP, C.c_size_t, C.c_int, C.POINTER(C.c_int), C.c_int]
     L.lv_remove_leading_trailing_nonalpha.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
     L.lv_resample.argtypes = [P, FPP, C.c_uint32, FP, C.c_int]
@@ -554,6 +559,23 @@ class Filter:
 
     def stop(self):
         self.L.lv_filter_stop(self.f)
+
+    def register_model(self, name: str, file: str | None):
+        """models_info() entry + find_model_bin_file result for update_model (None: listed, not on disk)."""
+        return self.L.lv_filter_register_model(self.f, name.encode(), file.encode() if file else None)
+
+    def update_model(self) -> int:
+        """update_whisper_model(gf): 0 = a context is loaded afterwards, 1 = the filter is left stopped."""
+        return self.L.lv_filter_update_model(self.f)
+
+    def model_state(self) -> dict:
+        a, b = C.create_string_buffer(1024), C.create_string_buffer(1024)
+        new, run, dtw = C.c_int(0), C.c_int(0), C.c_int(0)
+        rc = self.L.lv_filter_model_state(self.f, a, len(a), b, len(b), C.byref(new), C.byref(run), C.byref(dtw))
+        if rc != 0:
+            raise RuntimeError("lv_filter_model_state failed")
+        return dict(model_path=a.value.decode(), file_loaded=b.value.decode(), loaded_new=bool(new.value),
+                    worker_running=bool(run.value), dtw=bool(dtw.value), context=bool(self.L.lv_filter_context(self.f)))
 
 
 def remove_leading_trailing_nonalpha(s: bytes) -> bytes:

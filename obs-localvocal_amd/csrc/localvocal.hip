@@ -430,6 +430,7 @@ int lv_filter_start(lv_filter *f, const char *model_path) {
         if (f->gf.whisper_context != nullptr) return -2;
         start_whisper_thread_with_path(&f->gf, model_path, "silero-vad/silero_vad.onnx");
         if (f->gf.whisper_context == nullptr) return -3;
+        f->gf.whisper_model_path = model_path;
         make_vad(f);  // keep the gate configured through lv_filter_set_vad_gate
         return 0;
     });
@@ -440,6 +441,35 @@ void lv_filter_stop(lv_filter *f) {
         shutdown_whisper_thread(&f->gf);
     } catch (...) {
     }
+}
+
+int lv_filter_register_model(lv_filter *f, const char *name, const char *file) {
+    if (!f || !name) return -1;
+    return lv_guard([&] {
+        f->gf.models_info[name] = file ? file : "";
+        return 0;
+    });
+}
+int lv_filter_update_model(lv_filter *f) {
+    if (!f) return -1;
+    return lv_guard([&] {
+        f->gf.context = &f->settings;
+        update_whisper_model(&f->gf);
+        if (f->gf.whisper_context != nullptr && f->gf.vad) make_vad(f);  // keep the gate configured through lv_filter_set_vad_gate
+        return f->gf.whisper_context != nullptr ? 0 : 1;
+    });
+}
+int lv_filter_model_state(lv_filter *f, char *model_path, size_t n_path, char *file_loaded, size_t n_file, int *loaded_new,
+                          int *worker_running, int *dtw) {
+    if (!f) return -1;
+    return lv_guard([&] {
+        if (model_path && n_path) snprintf(model_path, n_path, "%s", f->gf.whisper_model_path.c_str());
+        if (file_loaded && n_file) snprintf(file_loaded, n_file, "%s", f->gf.whisper_model_file_currently_loaded.c_str());
+        if (loaded_new) *loaded_new = f->gf.whisper_model_loaded_new ? 1 : 0;
+        if (worker_running) *worker_running = f->gf.whisper_thread.joinable() ? 1 : 0;
+        if (dtw) *dtw = f->gf.enable_token_ts_dtw ? 1 : 0;
+        return 0;
+    });
 }
 
 int lv_vad_speech_timestamps(lv_filter *f, const float *pcm, size_t n, int reset_state, int *pairs, int cap) {

@@ -244,6 +244,12 @@ struct transcription_filter_data {
     std::function<void(const float *pcm32f_data, size_t n, uint64_t t0, uint64_t t1, int vad_state)> inferenceRequestObserver;
 
     std::string whisper_model_file_currently_loaded;
+    bool whisper_model_loaded_new = false;
+    // what update_whisper_model reads through gf->context in the reference: the source's settings (obs_data_t stand-in) and
+    // the model catalogue (models_info() + find_model_bin_file: catalogue name -> local file, "" = listed but not on disk;
+    // the downloader behind it is out of scope)
+    lv_settings *context = nullptr;
+    std::map<std::string, std::string> models_info;
 
     std::thread whisper_thread;
     std::mutex whisper_buf_mutex;
@@ -273,6 +279,8 @@ bool whisper_loop_iteration(transcription_filter_data *gf, vad_state &current_va
 void start_whisper_thread_with_path(struct transcription_filter_data *gf, const std::string &whisper_model_path,
                                     const char *silero_vad_model_file);
 void shutdown_whisper_thread(struct transcription_filter_data *gf);
+// whisper-model-utils.cpp:12-142: reload the model when the settings name another one (or an external file, or the DTW flag)
+void update_whisper_model(struct transcription_filter_data *gf);
 void shutdown_whisper_context(struct transcription_filter_data *gf);
 std::string to_timestamp(uint64_t t_ms_offset);
 

@@ -14,7 +14,7 @@
 #define MAX_MS_WORK_BUFFER 11000  // whisper-processing.h:12
 
 namespace {
-constexpr int kLogWarn = mw::LOG_WARN, kLogError = mw::LOG_ERROR, kLogDebug = mw::LOG_DEBUG;
+constexpr int kLogInfo = mw::LOG_INFO, kLogWarn = mw::LOG_WARN, kLogError = mw::LOG_ERROR, kLogDebug = mw::LOG_DEBUG;
 constexpr size_t kF = sizeof(float);
 }  // namespace
 
@@ -712,8 +712,7 @@ void start_whisper_thread_with_path(transcription_filter_data *gf, const std::st
         mw::log_msg(kLogError, "Failed to initialize whisper context\n");
         return;
     }
-    gf->whisper_model_file_currently_loaded = whisper_model_path;
-    gf->whisper_model_path = whisper_model_path;
+    gf->whisper_model_file_currently_loaded = whisper_model_path;  // (gf->whisper_model_path is the CALLER's to set, as in the reference)
     std::thread new_whisper_thread(whisper_loop, gf);
     gf->whisper_thread.swap(new_whisper_thread);
 }
@@ -727,4 +726,71 @@ void shutdown_whisper_thread(transcription_filter_data *gf) {
     }
     if (gf->whisper_thread.joinable()) gf->whisper_thread.join();
     gf->whisper_model_path.clear();
+}
+
+// update_whisper_model (/root/reference/src/whisper-utils/whisper-model-utils.cpp:12-142), decision for decision:
+//   * the settings' "whisper_model_path" is a catalogue name, or contains "!!!external!!!" and the file comes from
+//     "whisper_model_path_external";
+//   * same name as loaded and not external: nothing happens (the worker keeps running);
+//   * another name: shutdown_whisper_thread FIRST (the context is freed under whisper_ctx_mutex, a worker parked in its
+//     250 ms wait is woken and joined), then the catalogue lookup — an unknown name or a file that is not on disk leaves
+//     the filter stopped (the reference opens its download dialog there; the downloader is out of scope);
+//   * external: an identical file that is already loaded is left alone, anything else is a restart;
+//   * a changed "dtw_token_timestamps" restarts the worker with gf->whisper_model_path — which shutdown_whisper_thread
+//     has just cleared, so, exactly like the reference, that restart fails ("Failed to initialize whisper context") and
+//     the filter stays stopped until the next call finds path "" != settings and loads the model with the new flag.
+void update_whisper_model(transcription_filter_data *gf) {
+    if (gf->context == nullptr) {
+        mw::log_msg(kLogError, "obs_source_t context is null\n");
+        return;
+    }
+    lv_settings *s = gf->context;
+    const std::string new_model_path = s->get_string("whisper_model_path");
+    const std::string external_model_file_path = s->get_string("whisper_model_path_external");
+    const bool new_dtw_timestamps = s->get_bool("dtw_token_timestamps");
+    const bool is_external_model = new_model_path.find("!!!external!!!") != std::string::npos;
+    if (!is_external_model && new_model_path.empty()) {
+        mw::log_msg(kLogWarn, "Whisper model path is empty\n");
+        return;
+    }
+    if (is_external_model && external_model_file_path.empty()) {
+        mw::log_msg(kLogWarn, "External model file path is empty\n");
+        return;
+    }
+    const char *silero = "models/silero-vad/silero_vad.onnx";
+    if (gf->whisper_model_path.empty() || gf->whisper_model_path != new_model_path || is_external_model) {
+        if (gf->whisper_model_path != new_model_path) {
+            mw::log_msg(kLogDebug, "model path changed from %s to %s\n", gf->whisper_model_path.c_str(), new_model_path.c_str());
+            gf->whisper_model_loaded_new = !gf->whisper_model_path.empty();  // a switch, not the initial load
+        }
+        if (!is_external_model) {
+            shutdown_whisper_thread(gf);
+            const auto it = gf->models_info.find(new_model_path);
+            if (it == gf->models_info.end()) {
+                mw::log_msg(kLogWarn, "Model '%s' does not exist\n", new_model_path.c_str());
+                return;
+            }
+            if (it->second.empty()) {
+                mw::log_msg(kLogWarn, "Whisper model does not exist (download is outside this library)\n");
+                return;
+            }
+            gf->whisper_model_path = new_model_path;
+            start_whisper_thread_with_path(gf, it->second, silero);
+        } else if (gf->whisper_model_file_currently_loaded == external_model_file_path) {
+            mw::log_msg(kLogInfo, "External model file is already loaded\n");
+            return;
+        } else {
+            shutdown_whisper_thread(gf);
+            gf->whisper_model_path = new_model_path;
+            start_whisper_thread_with_path(gf, external_model_file_path, silero);
+        }
+    } else {
+        mw::log_msg(kLogDebug, "Model path did not change: %s == %s\n", gf->whisper_model_path.c_str(), new_model_path.c_str());
+    }
+    if (new_dtw_timestamps != gf->enable_token_ts_dtw) {
+        mw::log_msg(kLogDebug, "dtw_token_timestamps changed from %d to %d\n", (int)gf->enable_token_ts_dtw, (int)new_dtw_timestamps);
+        gf->enable_token_ts_dtw = new_dtw_timestamps;
+        shutdown_whisper_thread(gf);
+        start_whisper_thread_with_path(gf, gf->whisper_model_path, silero);
+    }
 }

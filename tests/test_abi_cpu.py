@@ -76,3 +76,21 @@ def test_missing_gpu_is_an_error_not_a_fallback(pkg, model_file):
         pytest.skip("GPU present")
     with pytest.raises(RuntimeError):
         pkg.Engine(model_file("micro.en"))
+
+
+def test_update_whisper_model_decisions_that_need_no_gpu(pkg):
+    # whisper-model-utils.cpp:38-47,75-79: empty name, empty external path, unknown / not-downloaded catalogue names
+    f = pkg.Filter()
+    try:
+        assert f.update_model() == 1                               # "Whisper model path is empty"
+        f.set_setting("whisper_model_path", "!!!external!!!")
+        assert f.update_model() == 1                               # "External model file path is empty"
+        f.set_setting("whisper_model_path", "No Such Model")
+        assert f.update_model() == 1                               # "Model '...' does not exist"
+        f.register_model("Listed", None)
+        f.set_setting("whisper_model_path", "Listed")
+        assert f.update_model() == 1                               # listed, not on disk (download dialog in the reference)
+        st = f.model_state()
+        assert st == dict(model_path="", file_loaded="", loaded_new=False, worker_running=False, dtw=False, context=False)
+    finally:
+        f.close()
