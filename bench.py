@@ -59,8 +59,9 @@ KERNEL_NAMES = {"qkv": "proj_ln_tile_kernel<rows,EPI_QKV,16>", "cross_q": "proj_
                 "cross_attn": "cross_attn_lean_kernel<rows>"}
 
 
-def gemv_bytes(cls: str, d: int, n_vocab: int, rows: int, wbytes: int, n_audio_ctx: int = 1500) -> int:
-    """Algorithmic HBM bytes of ONE launch of a decode-step kernel class."""
+def gemv_bytes(cls: str, d: int, n_vocab: int, rows: int, wbytes: int, n_audio_ctx: int = 1500, fp8: bool = False) -> int:
+    """Algorithmic HBM bytes of ONE launch of a decode-step kernel class.  fp8: the matrix is read as
+    e4m3 bytes + one fp32 scale per row; activations, caches and the cross K / V stay bf16."""
     if cls == "cross_attn":  # one layer's cross K and V of the stream (shared by the rows) + q in + rows out
         return 2 * n_audio_ctx * d * wbytes + rows * d * 4 * 2
     N, K = {"qkv": (3 * d, d), "attn_out": (d, d), "cross_q": (d, d), "fc1": (4 * d, d), "fc2": (d, 4 * d),
@@ -68,7 +69,7 @@ def gemv_bytes(cls: str, d: int, n_vocab: int, rows: int, wbytes: int, n_audio_c
     resid = cls in ("attn_out", "fc2")
     x_b = 2 if resid and wbytes == 2 else 4   # rows between attention / MLP kernels and the residual projections are bf16
     o_b = 2 if cls == "fc1" and wbytes == 2 else 4
-    return N * K * wbytes + N * 4 + rows * K * x_b + rows * N * o_b * (2 if resid else 1)
+    return N * K * (1 if fp8 else wbytes) + N * (8 if fp8 else 4) + rows * K * x_b + rows * N * o_b * (2 if resid else 1)
 
 
 def cpu_baseline(model_path: str, pcm: np.ndarray, beam: int, decode_steps: int, sample_steps: int, threads: int, reps: int = 3):
@@ -225,7 +226,8 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--model", default="large-v3")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp8"],
+                    help="fp8: bf16 engine with the decoder's projection / logits matrices streamed as e4m3 (BASELINE configs[4])")
     ap.add_argument("--beam", type=int, default=5)
     ap.add_argument("--decode-steps", type=int, default=128)
     ap.add_argument("--roofline-class", default="cross_attn", choices=sorted(GEMV_CLASSES),
@@ -300,7 +302,7 @@ def main():
 
     torch.cuda.set_device(local_rank)
     t0 = time.time()
-    eng = pkg.Engine(model_path, precision=pkg.PRECISION_BF16 if a.precision == "bf16" else pkg.PRECISION_FP32,
+    eng = pkg.Engine(model_path, precision={"bf16": pkg.PRECISION_BF16, "fp32": pkg.PRECISION_FP32, "fp8": pkg.PRECISION_FP8}[a.precision],
                      device=local_rank)
     t_load = time.time() - t0
     eng.set_force_decode_steps(a.decode_steps)
@@ -386,7 +388,7 @@ def main():
         audio_s = 30.0 * a.steps * n_gpus
         value = audio_s / elapsed
         ms_per_step = 1000.0 * elapsed / a.steps
-        wbytes = 2 if a.precision == "bf16" else 4
+        wbytes = 4 if a.precision == "fp32" else 2
         rows = a.beam
         # HBM bytes per launch from the PMC passes (separate rocprofv3 --pmc runs of this command, summarised by
         # tools/pmc_summary.py with the gfx950 FETCH_SIZE correction); null when the summary is not in the tree
@@ -403,7 +405,7 @@ def main():
 
         def roof(k):
             n_l, ms, _nw = prof[k]
-            b_launch = gemv_bytes(k, eng.n_text_state, eng.n_vocab, rows, wbytes)
+            b_launch = gemv_bytes(k, eng.n_text_state, eng.n_vocab, rows, wbytes, fp8=a.precision == "fp8")
             avg_ms = ms / max(n_l, 1)
             achieved = b_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
             return {"bound": "hbm", "kernel": KERNEL_NAMES[k], "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",

@@ -18,12 +18,15 @@ extern "C" {
 
 enum mw_precision {
     MW_PRECISION_BF16 = 0, /* bf16 weights / MFMA operands / KV caches, fp32 accumulate + residual stream */
-    MW_PRECISION_FP32 = 1  /* exact fp32 everywhere (f32 MFMA): the bit-exact-token mode for tiny/base */
+    MW_PRECISION_FP32 = 1, /* exact fp32 everywhere (f32 MFMA): the bit-exact-token mode for tiny/base */
+    MW_PRECISION_FP8 = 2   /* MW_PRECISION_BF16 with the decoder's projection matrices and the logits matrix quantised to OCP
+                              e4m3 at load (one power-of-two scale per output row) and streamed as bytes by the decode-step
+                              kernels (bf16 activations, fp32 accumulate); the encoder keeps bf16 weights */
 };
 
 /* Same as whisper_init_from_file_with_params (whisper-processing.cpp:112) with the arithmetic mode made
    explicit.  whisper_init_* use MW_PRECISION_BF16 unless the environment variable
-   MI355_WHISPER_PRECISION is "fp32". */
+   MI355_WHISPER_PRECISION is "fp32" or "fp8". */
 struct whisper_context *mw_init_from_file(const char *path_model, int gpu_device, int precision);
 struct whisper_context *mw_init_from_buffer(const void *buffer, size_t size, int gpu_device, int precision);
 /* A further context (one more audio stream / OBS source) on src's GPU that SHARES src's HBM-resident weights: nothing is

@@ -22,6 +22,7 @@ CSRC = os.path.join(_HERE, "csrc")
 
 PRECISION_BF16 = 0
 PRECISION_FP32 = 1
+PRECISION_FP8 = 2
 SAMPLING_GREEDY = 0
 SAMPLING_BEAM_SEARCH = 1
 

@@ -50,17 +50,29 @@ template <typename F> int guarded(const char *what, F &&f) {
     }
 }
 
-DType default_precision() {
+// what a context computes in: element type of the matrix weights / activations, and whether the decoder's matrices are
+// additionally kept (and streamed) as e4m3
+struct Precision {
+    DType wt;
+    bool fp8;
+    bool operator==(const Precision &o) const { return wt == o.wt && fp8 == o.fp8; }
+};
+Precision precision_of(int mw_precision) {
+    return Precision{mw_precision == MW_PRECISION_FP32 ? DType::F32 : DType::BF16, mw_precision == MW_PRECISION_FP8};
+}
+Precision default_precision() {
     const char *e = getenv("MI355_WHISPER_PRECISION");
-    return (e && (strcmp(e, "fp32") == 0 || strcmp(e, "f32") == 0)) ? DType::F32 : DType::BF16;
+    if (e && (strcmp(e, "fp32") == 0 || strcmp(e, "f32") == 0)) return precision_of(MW_PRECISION_FP32);
+    if (e && (strcmp(e, "fp8") == 0 || strcmp(e, "f8") == 0)) return precision_of(MW_PRECISION_FP8);
+    return precision_of(MW_PRECISION_BF16);
 }
 
-whisper_context *init_from_buffer(const void *buffer, size_t size, int device, DType wt) {
+whisper_context *init_from_buffer(const void *buffer, size_t size, int device, Precision wt) {
     whisper_context *ctx = nullptr;
     const int rc = guarded("whisper_init", [&]() {
         if (!buffer || size < 64) throw std::runtime_error("empty model buffer");
         std::unique_ptr<whisper_context> w(new whisper_context());
-        w->c = create_context((const unsigned char *)buffer, size, device, wt);
+        w->c = create_context((const unsigned char *)buffer, size, device, wt.wt, wt.fp8);
         ctx = w.release();
         return 0;
     });
@@ -72,7 +84,7 @@ whisper_context *init_from_buffer(const void *buffer, size_t size, int device, D
 struct SharedModelEntry {
     std::string path;
     int device;
-    DType wt;
+    Precision wt;
     long long size, mtime_ns;
     Model view;  // owners reset
     std::weak_ptr<void> arena, mel_tab;
@@ -100,7 +112,7 @@ whisper_context *init_shared_from(const Context &src) {
     return rc == 0 ? ctx : nullptr;
 }
 
-whisper_context *init_from_file(const char *path, int device, DType wt) {
+whisper_context *init_from_file(const char *path, int device, Precision wt) {
     if (!path) return nullptr;
     long long fsize = 0, fmtime = 0;
     const bool have_id = getenv("MI355_WHISPER_NO_SHARED_WEIGHTS") == nullptr && file_identity(path, fsize, fmtime);
@@ -220,10 +232,10 @@ struct whisper_context *whisper_init_from_buffer_with_params(void *buffer, size_
     return init_from_buffer(buffer, buffer_size, params.gpu_device, default_precision());
 }
 struct whisper_context *mw_init_from_file(const char *path_model, int gpu_device, int precision) {
-    return init_from_file(path_model, gpu_device, precision == MW_PRECISION_FP32 ? DType::F32 : DType::BF16);
+    return init_from_file(path_model, gpu_device, precision_of(precision));
 }
 struct whisper_context *mw_init_from_buffer(const void *buffer, size_t size, int gpu_device, int precision) {
-    return init_from_buffer(buffer, size, gpu_device, precision == MW_PRECISION_FP32 ? DType::F32 : DType::BF16);
+    return init_from_buffer(buffer, size, gpu_device, precision_of(precision));
 }
 struct whisper_context *mw_init_shared(struct whisper_context *src) {
     if (!src || !src->c) return nullptr;

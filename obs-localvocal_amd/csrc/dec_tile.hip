@@ -70,7 +70,22 @@ struct Proj {
     const bf16_t *W;
     const float *bias;
     int N, K;
+    // fp8 mode (template parameter W8): the same matrix as OCP e4m3 bytes, one power-of-two scale per output row
+    const unsigned char *W8;
+    const float *ws;
 };
+
+// 16 e4m3 bytes -> 16 bf16 (exact: 4 significant bits): v_cvt_pk_f32_fp8 per byte pair, the high halves of the two floats
+// packed by one v_perm_b32.  The row scale is applied to the finished sum (a power of two: the result is the same to the bit
+// as multiplying bf16 weights that already carry it).
+__device__ __forceinline__ unsigned fp8x2_to_bf16x2(unsigned u, bool hi) {
+    const auto f = hi ? __builtin_amdgcn_cvt_pk_f32_fp8((int)u, true) : __builtin_amdgcn_cvt_pk_f32_fp8((int)u, false);
+    return __builtin_amdgcn_perm(__float_as_uint(f[1]), __float_as_uint(f[0]), 0x07060302u);
+}
+__device__ __forceinline__ void fp8x16_to_bf16(const uint4 &u, uint4 &lo, uint4 &hi) {
+    lo = make_uint4(fp8x2_to_bf16x2(u.x, false), fp8x2_to_bf16x2(u.x, true), fp8x2_to_bf16x2(u.y, false), fp8x2_to_bf16x2(u.y, true));
+    hi = make_uint4(fp8x2_to_bf16x2(u.z, false), fp8x2_to_bf16x2(u.z, true), fp8x2_to_bf16x2(u.w, false), fp8x2_to_bf16x2(u.w, true));
+}
 
 using bf16x8b = __attribute__((ext_vector_type(8))) __bf16;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -142,7 +157,7 @@ __device__ __forceinline__ void proj_finish(float v, int erow, int n_e, const Pr
 // 2w and 2w+1 as consecutive 1 KB pieces — and re-read from LDS in the MFMA B-fragment layout.  Loading the
 // fragments straight from global memory touches 64 cache lines per instruction (16 bytes of each) instead of
 // 8 and was 1.3-1.4 us slower per launch (tools/microbench/mb_latency, "B-fragment pattern").
-template <int NB, int EPI, int FR, bool DESC>
+template <int NB, int EPI, int FR, bool DESC, bool W8>
 __device__ __forceinline__ void proj_ln_tile(const Proj &p, const float *xin, const float *ln_w, const float *ln_b, int n, const Epi &e,
                                              bf16_t *xs, bf16_t *wt, float *red, unsigned long long *stamp) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
@@ -165,11 +180,16 @@ __device__ __forceinline__ void proj_ln_tile(const Proj &p, const float *xin, co
         gw[i] = *reinterpret_cast<const float4 *>(ln_w + c);
         gb[i] = *reinterpret_cast<const float4 *>(ln_b + c);
     }
-    constexpr int RPW = FR / 8, WJ = (RPW * 160 + 63) / 64;  // weight rows per wave, load instructions per wave (K <= 1280)
+    // weight rows per wave, load instructions per wave (K <= 1280: 160 sixteen-byte pieces per bf16 row, 80 per e4m3 row)
+    constexpr int RPW = FR / 8, WJ = (RPW * (W8 ? 80 : 160) + 63) / 64;
     constexpr int TL = FR > 16 ? FR / 16 : 1;                // 16-feature MFMA tiles per workgroup
     uint4 w[WJ];
-    const int wpieces = RPW * (K >> 3);  // 16-byte pieces in the wave's row(s)
-    {
+    const int wpieces = RPW * (K >> (W8 ? 4 : 3));  // 16-byte pieces in the wave's row(s)
+    if constexpr (W8) {
+        const unsigned char *wbase = p.W8 + (long)(tile * FR + RPW * wave) * K;
+#pragma unroll
+        for (int j = 0; j < WJ; ++j) w[j] = ld_stream16(wbase + 16 * min(lane + 64 * j, wpieces - 1));
+    } else {
         const bf16_t *wbase = p.W + (long)(tile * FR + RPW * wave) * K;
 #pragma unroll
         for (int j = 0; j < WJ; ++j) w[j] = ld_stream16(wbase + 8 * min(lane + 64 * j, wpieces - 1));
@@ -177,6 +197,8 @@ __device__ __forceinline__ void proj_ln_tile(const Proj &p, const float *xin, co
     const int et = tid >> 8, el = (tid & 255) >> 2, er = tid & 3, erow = 4 * (el >> 4) + er;  // finisher: tile, lane, register
     const int n_e = tile * FR + min(16 * et + (el & 15), FR - 1);
     const float bias_e = p.bias ? p.bias[n_e] : 0.0f;
+    float ws_e = 1.0f;
+    if constexpr (W8) ws_e = p.ws[n_e];
     long kv_off = 0;
     bf16_t *kc_e = e.kc, *vc_e = e.vc;
     if constexpr (EPI == EPI_QKV) {
@@ -221,9 +243,18 @@ __device__ __forceinline__ void proj_ln_tile(const Proj &p, const float *xin, co
     // ---- the wave's two weight rows -> LDS ----
 #pragma unroll
     for (int j = 0; j < WJ; ++j) {
-        const int pc = lane + 64 * j, half = K >> 3;  // pieces per row
+        const int pc = lane + 64 * j, half = K >> (W8 ? 4 : 3);  // pieces per row
         const int r = (pc >= half ? 1 : 0) + (pc >= 2 * half ? 1 : 0) + (pc >= 3 * half ? 1 : 0);
-        if (pc < wpieces) *reinterpret_cast<uint4 *>(wt + (RPW * wave + r) * ldxs + 8 * (pc - r * half)) = w[j];
+        if constexpr (W8) {
+            uint4 lo, hi;
+            fp8x16_to_bf16(w[j], lo, hi);
+            if (pc < wpieces) {
+                *reinterpret_cast<uint4 *>(wt + (RPW * wave + r) * ldxs + 16 * (pc - r * half)) = lo;
+                *reinterpret_cast<uint4 *>(wt + (RPW * wave + r) * ldxs + 16 * (pc - r * half) + 8) = hi;
+            }
+        } else {
+            if (pc < wpieces) *reinterpret_cast<uint4 *>(wt + (RPW * wave + r) * ldxs + 8 * (pc - r * half)) = w[j];
+        }
     }
     lds_sync();
     if (stamp && tid == 0) stamp[1] = wall_clock64();
@@ -256,6 +287,7 @@ __device__ __forceinline__ void proj_ln_tile(const Proj &p, const float *xin, co
         float r = 0.0f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) r += red[((et * 8 + k) * 64 + el) * 4 + er];
+        if constexpr (W8) r *= ws_e;
         r += bias_e;
         if constexpr (EPI == EPI_QKV) {
             const int d = e.d;
@@ -275,7 +307,7 @@ __device__ __forceinline__ void proj_ln_tile(const Proj &p, const float *xin, co
 // 64*SPC contiguous bytes); each chunk is transposed into the fragment layout through a wave-private LDS tile
 // (LDS operations of one wave execute in order: no barrier), so the only workgroup barrier is the one before
 // the 8 partial tiles are summed.
-template <int NB, int SPC, int CH, int FR>
+template <int NB, int SPC, int CH, int FR, bool W8>
 __device__ __forceinline__ void proj_res_tile(const Proj &p, const bf16_t *xin, int n, const Epi &e, bf16_t *lds_t, float *red,
                                               unsigned long long *stamp) {
     constexpr int KC = 32 * SPC, LDT = KC + 8, PPR = 4 * SPC;  // k per chunk, LDS row stride, 16-byte pieces per row segment
@@ -285,7 +317,8 @@ __device__ __forceinline__ void proj_res_tile(const Proj &p, const bf16_t *xin, 
     constexpr int XST = XCH ? CH : 1;                            // x stages
     constexpr int XLD = (XCH ? KC : CH * KC) + 8, XPR = XCH ? PPR : PPR * CH;  // row stride, pieces per row of a stage
     constexpr int XI = (NB * XPR + 63) / 64;                     // x load instructions per stage
-    constexpr int WI = (FR * PPR + 63) / 64;                     // weight load instructions per chunk (FR feature rows per workgroup)
+    constexpr int PPW = W8 ? 2 * SPC : PPR;                      // 16-byte pieces per WEIGHT row segment (e4m3: 16 k per piece)
+    constexpr int WI = (FR * PPW + 63) / 64;                     // weight load instructions per chunk (FR feature rows per workgroup)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
     const int K = p.K, tile = blockIdx.x, kw = wave * CH * KC;
     u32x4v xv[XST][XI];  // first-class vectors: as HIP uint4 structs this array was not split into registers and went through
@@ -302,12 +335,15 @@ __device__ __forceinline__ void proj_res_tile(const Proj &p, const bf16_t *xin, 
     const float res_e = e.res[(long)(erow < n ? erow : 0) * p.N + n_e];
     const float bias_v = (p.bias ? p.bias : e.res)[n_e];  // unconditional load: a branch here would split the load block
     const float bias_e = p.bias ? bias_v : 0.0f;
+    float ws_e = 1.0f;
+    if constexpr (W8) ws_e = p.ws[n_e];
 #pragma unroll
     for (int c = 0; c < CH; ++c)
 #pragma unroll
         for (int j = 0; j < WI; ++j) {
-            const int pc = min(lane + 64 * j, FR * PPR - 1);
-            w[c][j] = ld_stream16(p.W + (long)(tile * FR + pc / PPR) * K + kw + c * KC + 8 * (pc % PPR));
+            const int pc = min(lane + 64 * j, FR * PPW - 1);
+            if constexpr (W8) w[c][j] = ld_stream16(p.W8 + (long)(tile * FR + pc / PPW) * K + kw + c * KC + 16 * (pc % PPW));
+            else w[c][j] = ld_stream16(p.W + (long)(tile * FR + pc / PPW) * K + kw + c * KC + 8 * (pc % PPW));
         }
     __builtin_amdgcn_sched_barrier(0);  // every load above is issued before anything below (no sinking next to the use)
     bf16_t *wt = lds_t + wave * (16 * LDT + NB * XLD), *xt = wt + 16 * LDT;
@@ -331,8 +367,15 @@ __device__ __forceinline__ void proj_res_tile(const Proj &p, const bf16_t *xin, 
         }
 #pragma unroll
         for (int j = 0; j < WI; ++j) {
-            const int pc = min(lane + 64 * j, FR * PPR - 1);  // surplus lanes rewrite the last piece
-            *reinterpret_cast<uint4 *>(wt + (pc / PPR) * LDT + 8 * (pc % PPR)) = w[c][j];
+            const int pc = min(lane + 64 * j, FR * PPW - 1);  // surplus lanes rewrite the last piece
+            if constexpr (W8) {
+                uint4 lo, hi;
+                fp8x16_to_bf16(w[c][j], lo, hi);
+                *reinterpret_cast<uint4 *>(wt + (pc / PPW) * LDT + 16 * (pc % PPW)) = lo;
+                *reinterpret_cast<uint4 *>(wt + (pc / PPW) * LDT + 16 * (pc % PPW) + 8) = hi;
+            } else {
+                *reinterpret_cast<uint4 *>(wt + (pc / PPW) * LDT + 8 * (pc % PPW)) = w[c][j];
+            }
         }
 #pragma unroll
         for (int s2 = 0; s2 < SPC; ++s2) {
@@ -349,6 +392,7 @@ __device__ __forceinline__ void proj_res_tile(const Proj &p, const bf16_t *xin, 
         float r = 0.0f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) r += red[(k * 64 + el) * 4 + er];
+        if constexpr (W8) r *= ws_e;
         st_agent(e.xout + (long)erow * p.N + n_e, r + bias_e + res_e);
     }
     if (stamp && tid == 0) stamp[3] = wall_clock64();
@@ -367,8 +411,8 @@ __device__ __forceinline__ void st_out(float *p, float v) { st_agent(p, v); }
 // per lane) through a ring of LRING chunks in registers and a wave-private LDS tile (fragment layout).
 constexpr int LKC = 128, LLD = LKC + 8, LRING = 3;
 
-template <int NB, int NCH>
-__device__ __forceinline__ void logits_tile(const bf16_t *W, const float *xin, const int *d_rows, const float *ln_w, const float *ln_b,
+template <int NB, int NCH, bool W8>
+__device__ __forceinline__ void logits_tile(const bf16_t *W, const unsigned char *W8p, const float *wsc, const float *xin, const int *d_rows, const float *ln_w, const float *ln_b,
                                             float *out, long ldo, int n, int N, bf16_t *xs, bf16_t *wtile) {
     constexpr int K = NCH * LKC, nf4 = K / 4, ldxs = K + 8;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
@@ -390,17 +434,24 @@ __device__ __forceinline__ void logits_tile(const bf16_t *W, const float *xin, c
         gb[i] = *reinterpret_cast<const float4 *>(ln_b + c);
     }
     // weight piece (chunk c, load j): row = (lane + 64 j) >> 4, 16-byte column = (lane + 64 j) & 15
-    const bf16_t *wl[4];
+    // (e4m3: 8 pieces of 16 k per row and chunk: row = (lane + 64 j) >> 3, column = (lane + 64 j) & 7, two loads per lane)
+    constexpr int WL = W8 ? 2 : 4;
+    const unsigned char *wl[WL];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < WL; ++j) {
         const int pc = lane + 64 * j;
-        wl[j] = W + (long)min(f0 + (pc >> 4), N - 1) * K + 8 * (pc & 15);  // rows beyond the vocabulary: clamped, never stored
+        // rows beyond the vocabulary: clamped, never stored
+        if constexpr (W8) wl[j] = W8p + (long)min(f0 + (pc >> 3), N - 1) * K + 16 * (pc & 7);
+        else wl[j] = reinterpret_cast<const unsigned char *>(W + (long)min(f0 + (pc >> 4), N - 1) * K + 8 * (pc & 15));
     }
-    uint4 w[NCH][4];
+    constexpr int CB = W8 ? LKC : 2 * LKC;  // bytes of a chunk in a weight row
+    float ws_e = 1.0f;
+    if constexpr (W8) ws_e = wsc[min(f0 + fr, N - 1)];
+    uint4 w[NCH][WL];
 #pragma unroll
     for (int c = 0; c < LRING && c < NCH; ++c)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) w[c][j] = ld_stream16(wl[j] + c * LKC);
+        for (int j = 0; j < WL; ++j) w[c][j] = ld_stream16(wl[j] + c * CB);
     __builtin_amdgcn_sched_barrier(0);
     // ---- LayerNorm of the wave's row(s) -> bf16 in LDS ----
 #pragma unroll
@@ -436,13 +487,20 @@ __device__ __forceinline__ void logits_tile(const bf16_t *W, const float *xin, c
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < WL; ++j) {
             const int pc = lane + 64 * j;
-            *reinterpret_cast<uint4 *>(wt + (pc >> 4) * LLD + 8 * (pc & 15)) = w[c][j];
+            if constexpr (W8) {
+                uint4 lo, hi;
+                fp8x16_to_bf16(w[c][j], lo, hi);
+                *reinterpret_cast<uint4 *>(wt + (pc >> 3) * LLD + 16 * (pc & 7)) = lo;
+                *reinterpret_cast<uint4 *>(wt + (pc >> 3) * LLD + 16 * (pc & 7) + 8) = hi;
+            } else {
+                *reinterpret_cast<uint4 *>(wt + (pc >> 4) * LLD + 8 * (pc & 15)) = w[c][j];
+            }
         }
         if (c + LRING < NCH) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) w[c + LRING][j] = ld_stream16(wl[j] + (c + LRING) * LKC);
+            for (int j = 0; j < WL; ++j) w[c + LRING][j] = ld_stream16(wl[j] + (c + LRING) * CB);
         }
 #pragma unroll
         for (int s2 = 0; s2 < 4; ++s2) {
@@ -455,7 +513,7 @@ __device__ __forceinline__ void logits_tile(const bf16_t *W, const float *xin, c
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = 4 * fq + r;
-        if (row < n && f0 + fr < N) out[(long)row * ldo + f0 + fr] = acc[r];
+        if (row < n && f0 + fr < N) out[(long)row * ldo + f0 + fr] = W8 ? acc[r] * ws_e : acc[r];
     }
 }
 
@@ -748,12 +806,13 @@ __device__ __forceinline__ void cross_attn_lean(const float *q, const bf16_t *kc
     cross_count_and_combine<NB, OT>(part, out, head_cnt, flag, row0, n, H, d, h, g * H + h, splits);
 }
 
-template <int NB, int NCH>
-__global__ __launch_bounds__(MT) void logits_tile_kernel(const bf16_t *W, const float *xin, const int *d_rows, const float *ln_w,
-                                                                    const float *ln_b, float *out, long ldo, int n, int N) {
+template <int NB, int NCH, bool W8>
+__global__ __launch_bounds__(MT) void logits_tile_kernel(const bf16_t *W, const unsigned char *W8p, const float *wsc, const float *xin,
+                                                         const int *d_rows, const float *ln_w, const float *ln_b, float *out, long ldo,
+                                                         int n, int N) {
     __shared__ __attribute__((aligned(16))) bf16_t xs[NB * (NCH * LKC + 8)];
     __shared__ __attribute__((aligned(16))) bf16_t wtile[8 * 16 * LLD];
-    logits_tile<NB, NCH>(W, xin, d_rows, ln_w, ln_b, out, ldo, n, N, xs, wtile);
+    logits_tile<NB, NCH, W8>(W, W8p, wsc, xin, d_rows, ln_w, ln_b, out, ldo, n, N, xs, wtile);
 }
 
 template <typename OT, bool DESC>
@@ -766,20 +825,20 @@ __global__ __launch_bounds__(MT) void self_attn_lean_kernel(const float *q, cons
 }
 
 
-template <int NB, int EPI, int FR, bool DESC>
+template <int NB, int EPI, int FR, bool DESC, bool W8>
 __global__ __launch_bounds__(MT) void proj_ln_tile_kernel(Proj p, const float *xin, const float *ln_w, const float *ln_b, int n,
                                                                      Epi e) {
     __shared__ __attribute__((aligned(16))) bf16_t xs[NB * (256 * LN_MAX_F4 + 8)];
     __shared__ __attribute__((aligned(16))) bf16_t wt[FR * (256 * LN_MAX_F4 + 8)];
     __shared__ __attribute__((aligned(16))) float red[(FR > 16 ? FR / 16 : 1) * 8 * 64 * 4];
-    proj_ln_tile<NB, EPI, FR, DESC>(p, xin, ln_w, ln_b, n, e, xs, wt, red, nullptr);
+    proj_ln_tile<NB, EPI, FR, DESC, W8>(p, xin, ln_w, ln_b, n, e, xs, wt, red, nullptr);
 }
 
-template <int NB, int SPC, int CH, int FR>
+template <int NB, int SPC, int CH, int FR, bool W8>
 __global__ __launch_bounds__(MT) void proj_res_tile_kernel(Proj p, const bf16_t *xin, int n, Epi e) {
     __shared__ __attribute__((aligned(16))) bf16_t lds_t[8 * (16 * (32 * SPC + 8) + NB * ((NB > 8 ? 1 : CH) * 32 * SPC + 8))];
     __shared__ __attribute__((aligned(16))) float red[8 * 64 * 4];
-    proj_res_tile<NB, SPC, CH, FR>(p, xin, n, e, lds_t, red, nullptr);
+    proj_res_tile<NB, SPC, CH, FR, W8>(p, xin, n, e, lds_t, red, nullptr);
 }
 
 template <int NB, typename OT, bool DESC>
@@ -826,53 +885,64 @@ void launch_proj_impl(const GemvArgs &a, const StepRow *rows, long kv_layer_off,
     MW_CHECK(a.x && a.W && a.out && a.n >= 1 && a.n <= STEP_MAX_ROWS, "proj_wg: 1..16 rows");
     MW_CHECK(a.N % 32 == 0 && a.K % 32 == 0 && a.ldx == a.K && !a.d_rows, "proj_wg: shape");
     const bool ln = a.ln_w != nullptr;
-    Proj p{(const bf16_t *)a.W, a.bias, a.N, a.K};
+    Proj p{(const bf16_t *)a.W, a.bias, a.N, a.K, (const unsigned char *)a.W8, a.w_scale};
+    const bool w8 = a.W8 != nullptr;
+    if (w8) MW_CHECK(a.w_scale && rows && a.K % 16 == 0, "proj_wg: e4m3 weights need row scales and the batched step");
     Epi e{};
     e.rows = rows;
     e.kv_layer_off = kv_layer_off;
     const dim3 block(MT);
-#define MW_PROJ_LN(NBv, EPIv, DESCv)                                                                                                \
+#define MW_PROJ_LN(NBv, EPIv, DESCv, W8v)                                                                                           \
     do {                                                                                                                            \
         if (a.N <= 1280)                                                                                                            \
-            hipLaunchKernelGGL((proj_ln_tile_kernel<NBv, EPIv, 8, DESCv>), dim3(a.N / 8), block, 0, st, p, (const float *)a.x, a.ln_w, \
-                               a.ln_b, a.n, e);                                                                                     \
+            hipLaunchKernelGGL((proj_ln_tile_kernel<NBv, EPIv, 8, DESCv, W8v>), dim3(a.N / 8), block, 0, st, p, (const float *)a.x, \
+                               a.ln_w, a.ln_b, a.n, e);                                                                             \
         else if (a.N > 4096)                                                                                                        \
-            hipLaunchKernelGGL((proj_ln_tile_kernel<NBv, EPIv, 32, DESCv>), dim3(a.N / 32), block, 0, st, p, (const float *)a.x,    \
-                               a.ln_w, a.ln_b, a.n, e);                                                                             \
+            hipLaunchKernelGGL((proj_ln_tile_kernel<NBv, EPIv, 32, DESCv, W8v>), dim3(a.N / 32), block, 0, st, p,                   \
+                               (const float *)a.x, a.ln_w, a.ln_b, a.n, e);                                                         \
         else                                                                                                                        \
-            hipLaunchKernelGGL((proj_ln_tile_kernel<NBv, EPIv, 16, DESCv>), dim3(a.N / 16), block, 0, st, p, (const float *)a.x,    \
-                               a.ln_w, a.ln_b, a.n, e);                                                                             \
+            hipLaunchKernelGGL((proj_ln_tile_kernel<NBv, EPIv, 16, DESCv, W8v>), dim3(a.N / 16), block, 0, st, p,                   \
+                               (const float *)a.x, a.ln_w, a.ln_b, a.n, e);                                                         \
     } while (0)
-#define MW_PROJ_LN_NB(EPIv, DESCv)                     \
-    do {                                                \
-        if (a.n == 1) MW_PROJ_LN(1, EPIv, DESCv);       \
-        else if (a.n <= 5) MW_PROJ_LN(5, EPIv, DESCv);  \
-        else MW_PROJ_LN(16, EPIv, DESCv);               \
+#define MW_PROJ_LN_W(EPIv, DESCv, W8v)                       \
+    do {                                                      \
+        if (a.n == 1) MW_PROJ_LN(1, EPIv, DESCv, W8v);        \
+        else if (a.n <= 5) MW_PROJ_LN(5, EPIv, DESCv, W8v);   \
+        else MW_PROJ_LN(16, EPIv, DESCv, W8v);                \
     } while (0)
+#define MW_PROJ_LN_NB(EPIv, DESCv) MW_PROJ_LN_W(EPIv, DESCv, false)
     if (ln) MW_CHECK(a.ln_b && a.K <= 256 * LN_MAX_F4, "proj_wg: LayerNorm classes need K <= 1280");
     if (a.qkv) {
         MW_CHECK(ln && a.N == 3 * a.K && a.ldo == a.K && a.kv_t == DType::BF16, "proj_wg: qkv class");
         MW_CHECK(rows || (a.kcache && a.vcache && a.d_slot && a.d_pos), "proj_wg: qkv class needs a cache");
         e.q = a.out; e.kc = (bf16_t *)a.kcache; e.vc = (bf16_t *)a.vcache; e.slot = a.d_slot; e.pos = a.d_pos; e.TC = a.n_text_ctx;
         e.d = a.K; e.qk_scale = a.qk_scale;
-        if (rows) MW_PROJ_LN_NB(EPI_QKV, true);
+        if (w8) MW_PROJ_LN_W(EPI_QKV, true, true);
+        else if (rows) MW_PROJ_LN_NB(EPI_QKV, true);
         else MW_PROJ_LN_NB(EPI_QKV, false);
     } else if (ln && a.act == ACT_GELU) {
         MW_CHECK(!a.R, "proj_wg: fc1 class");
         e.hout = (bf16_t *)a.out; e.fout = a.out; e.ldo = (int)a.ldo;
-        if (a.out_bf16) MW_PROJ_LN_NB(EPI_GELU_BF16, false);
+        if (w8) {
+            MW_CHECK(a.out_bf16, "proj_wg: e4m3 fc1 writes bf16");
+            MW_PROJ_LN_W(EPI_GELU_BF16, false, true);
+        } else if (a.out_bf16) MW_PROJ_LN_NB(EPI_GELU_BF16, false);
         else MW_PROJ_LN_NB(EPI_GELU_F32, false);
     } else if (ln) {
         MW_CHECK(!a.R && a.ldo == a.N && a.act == ACT_NONE, "proj_wg: cross-q class");
         e.fout = a.out; e.scale = a.out_scale;
-        MW_PROJ_LN_NB(EPI_SCALE, false);
+        if (w8) MW_PROJ_LN_W(EPI_SCALE, false, true);
+        else MW_PROJ_LN_NB(EPI_SCALE, false);
     } else {
         MW_CHECK(a.x_bf16 && a.R && a.ldo == a.N && a.act == ACT_NONE && a.out_scale == 1.0f, "proj_wg: residual class");
         e.res = a.R; e.xout = a.out;
         const int ch = a.K > 1280 ? 4 : 1, spc = a.K / (256 * ch);  // K = 8 waves x CH chunks x SPC steps x 32
         MW_CHECK(a.K == 256 * ch * spc && spc >= 2 && spc <= 5, "proj_wg: residual class needs K = 256 * {1,4} * {2..5}");
-#define MW_RES(NBv, SPCv, CHv) \
-    hipLaunchKernelGGL((proj_res_tile_kernel<NBv, SPCv, CHv, 8>), dim3(a.N / 8), block, 0, st, p, (const bf16_t *)a.x, a.n, e)
+#define MW_RES(NBv, SPCv, CHv)                                                                                                        \
+    do {                                                                                                                              \
+        if (w8) hipLaunchKernelGGL((proj_res_tile_kernel<NBv, SPCv, CHv, 8, true>), dim3(a.N / 8), block, 0, st, p, (const bf16_t *)a.x, a.n, e); \
+        else hipLaunchKernelGGL((proj_res_tile_kernel<NBv, SPCv, CHv, 8, false>), dim3(a.N / 8), block, 0, st, p, (const bf16_t *)a.x, a.n, e);  \
+    } while (0)
 #define MW_RES_CH(NBv, SPCv)              \
     do {                                   \
         if (ch == 1) MW_RES(NBv, SPCv, 1); \
@@ -895,6 +965,7 @@ void launch_proj_impl(const GemvArgs &a, const StepRow *rows, long kv_layer_off,
 #undef MW_RES
     }
 #undef MW_PROJ_LN_NB
+#undef MW_PROJ_LN_W
 #undef MW_PROJ_LN
     MW_HIP(hipGetLastError());
 }
@@ -954,9 +1025,18 @@ bool logits_tile_supported(const GemvArgs &a) {
 void launch_logits_tile(const GemvArgs &a, hipStream_t st) {
     MW_CHECK(logits_tile_supported(a), "logits_tile: shape");
     const dim3 grid(ceil_div(a.N, 128)), block(MT);
-#define MW_LT(NBv, NCHv)                                                                                                     \
-    hipLaunchKernelGGL((logits_tile_kernel<NBv, NCHv>), grid, block, 0, st, (const bf16_t *)a.W, a.x, a.d_rows, a.ln_w, a.ln_b, \
-                       a.out, a.ldo, a.n, a.N)
+    const bool w8 = a.W8 != nullptr;
+    if (w8) MW_CHECK(a.w_scale != nullptr, "logits_tile: e4m3 weights need row scales");
+#define MW_LT(NBv, NCHv)                                                                                                          \
+    do {                                                                                                                          \
+        if (w8)                                                                                                                   \
+            hipLaunchKernelGGL((logits_tile_kernel<NBv, NCHv, true>), grid, block, 0, st, (const bf16_t *)a.W,                    \
+                               (const unsigned char *)a.W8, a.w_scale, a.x, a.d_rows, a.ln_w, a.ln_b, a.out, a.ldo, a.n, a.N);    \
+        else                                                                                                                      \
+            hipLaunchKernelGGL((logits_tile_kernel<NBv, NCHv, false>), grid, block, 0, st, (const bf16_t *)a.W,                   \
+                               (const unsigned char *)nullptr, (const float *)nullptr, a.x, a.d_rows, a.ln_w, a.ln_b, a.out,      \
+                               a.ldo, a.n, a.N);                                                                                  \
+    } while (0)
 #define MW_LT_NB(NCHv)                     \
     do {                                    \
         if (a.n == 1) MW_LT(1, NCHv);       \

@@ -49,11 +49,12 @@ Context::~Context() {
 }
 
 namespace {
-std::unique_ptr<Context> create_context_impl(const unsigned char *data, size_t size, int device, DType wt, const Context *share);
+std::unique_ptr<Context> create_context_impl(const unsigned char *data, size_t size, int device, DType wt, const Context *share,
+                                             bool fp8 = false);
 }
 
-std::unique_ptr<Context> create_context(const unsigned char *data, size_t size, int device, DType wt) {
-    return create_context_impl(data, size, device, wt, nullptr);
+std::unique_ptr<Context> create_context(const unsigned char *data, size_t size, int device, DType wt, bool fp8) {
+    return create_context_impl(data, size, device, wt, nullptr, fp8);
 }
 
 // A further stream context on the same GPU: its Model is a view of `src`'s HBM-resident weights (reference-counted,
@@ -63,7 +64,8 @@ std::unique_ptr<Context> create_shared_context(const Context &src) {
 }
 
 namespace {
-std::unique_ptr<Context> create_context_impl(const unsigned char *data, size_t size, int device, DType wt, const Context *share) {
+std::unique_ptr<Context> create_context_impl(const unsigned char *data, size_t size, int device, DType wt, const Context *share,
+                                             bool fp8) {
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
         throw std::runtime_error("no HIP device available: this engine has no CPU path");
@@ -78,7 +80,7 @@ std::unique_ptr<Context> create_context_impl(const unsigned char *data, size_t s
     MW_HIP(hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking));
     (void)mel_noalloc_init(device);  // device address of the allocation-free mel entry's scratch array, once per device
     if (share) c->model = share->model;
-    else load_model(c->model, data, size, wt, c->st);
+    else load_model(c->model, data, size, wt, c->st, fp8);
     const HParams &hp = c->model.hp;
     const size_t d = hp.n_audio_state, T = hp.n_audio_ctx, ws = dtype_size(wt), H = hp.n_audio_head;
     const size_t L = hp.n_text_layer, TC = hp.n_text_ctx, nv = hp.n_vocab;
@@ -528,7 +530,7 @@ void Hub::run(Lane &ln, const std::vector<StepRequest *> &batch) {
             const long kv_off = (long)(l * kv_layer);
             {
                 GemvArgs g;  // LN + Q|K|V; K and V go straight into each row's cache
-                g.x = d_x; g.ldx = d; g.n = R; g.W = e.qkv_w; g.bias = e.qkv_b; g.N = 3 * d; g.K = d;
+                g.x = d_x; g.ldx = d; g.n = R; g.W = e.qkv_w; if (m.dec_fp8) { g.W8 = e.qkv_w8; g.w_scale = e.qkv_s; } g.bias = e.qkv_b; g.N = 3 * d; g.K = d;
                 g.ln_w = e.ln1_w; g.ln_b = e.ln1_b; g.out = d_q; g.ldo = d; g.qkv = 1; g.qk_scale = qk_scale;
                 g.kv_t = DType::BF16; g.n_text_ctx = TC; g.tag = GEMV_QKV;
                 proj(g, kv_off);
@@ -537,13 +539,13 @@ void Hub::run(Lane &ln, const std::vector<StepRequest *> &batch) {
             if (dup_tag == GEMV_N_TAGS && prof_tag < 0) launch_self_attn_batch(d_q, d_blk, kv_off, d_attd, R, H, d, TC, st);
             {
                 GemvArgs g;
-                g.x = (const float *)d_attd; g.x_bf16 = 1; g.ldx = d; g.n = R; g.W = e.out_w; g.bias = e.out_b; g.N = d; g.K = d;
+                g.x = (const float *)d_attd; g.x_bf16 = 1; g.ldx = d; g.n = R; g.W = e.out_w; if (m.dec_fp8) { g.W8 = e.out_w8; g.w_scale = e.out_s; } g.bias = e.out_b; g.N = d; g.K = d;
                 g.out = d_x; g.ldo = d; g.R = d_x; g.tag = GEMV_ATTN_OUT;
                 proj(g, 0);
             }
             {
                 GemvArgs g;  // LN + cross query (scaled)
-                g.x = d_x; g.ldx = d; g.n = R; g.W = e.cq_w; g.bias = e.cq_b; g.N = d; g.K = d;
+                g.x = d_x; g.ldx = d; g.n = R; g.W = e.cq_w; if (m.dec_fp8) { g.W8 = e.cq_w8; g.w_scale = e.cq_s; } g.bias = e.cq_b; g.N = d; g.K = d;
                 g.ln_w = e.lnc_w; g.ln_b = e.lnc_b; g.out = d_q; g.ldo = d; g.out_scale = qk_scale; g.tag = GEMV_CROSS_Q;
                 proj(g, 0);
             }
@@ -555,26 +557,26 @@ void Hub::run(Lane &ln, const std::vector<StepRequest *> &batch) {
                 launch_cross_attn_batch(d_q, d_blk, k_off, v_off, d_part, d_attd, d_head_cnt, R, G, H, d, n_ctx_max, splits, st);
             {
                 GemvArgs g;
-                g.x = (const float *)d_attd; g.x_bf16 = 1; g.ldx = d; g.n = R; g.W = e.co_w; g.bias = e.co_b; g.N = d; g.K = d;
+                g.x = (const float *)d_attd; g.x_bf16 = 1; g.ldx = d; g.n = R; g.W = e.co_w; if (m.dec_fp8) { g.W8 = e.co_w8; g.w_scale = e.co_s; } g.bias = e.co_b; g.N = d; g.K = d;
                 g.out = d_x; g.ldo = d; g.R = d_x; g.tag = GEMV_ATTN_OUT;
                 proj(g, 0);
             }
             {
                 GemvArgs g;
-                g.x = d_x; g.ldx = d; g.n = R; g.W = e.fc1_w; g.bias = e.fc1_b; g.N = 4 * d; g.K = d;
+                g.x = d_x; g.ldx = d; g.n = R; g.W = e.fc1_w; if (m.dec_fp8) { g.W8 = e.fc1_w8; g.w_scale = e.fc1_s; } g.bias = e.fc1_b; g.N = 4 * d; g.K = d;
                 g.ln_w = e.ln2_w; g.ln_b = e.ln2_b; g.act = ACT_GELU; g.out = (float *)d_ffd; g.out_bf16 = 1; g.ldo = 4 * d; g.tag = GEMV_FC1;
                 proj(g, 0);
             }
             {
                 GemvArgs g;
-                g.x = (const float *)d_ffd; g.x_bf16 = 1; g.ldx = 4 * d; g.n = R; g.W = e.fc2_w; g.bias = e.fc2_b; g.N = d; g.K = 4 * d;
+                g.x = (const float *)d_ffd; g.x_bf16 = 1; g.ldx = 4 * d; g.n = R; g.W = e.fc2_w; if (m.dec_fp8) { g.W8 = e.fc2_w8; g.w_scale = e.fc2_s; } g.bias = e.fc2_b; g.N = d; g.K = 4 * d;
                 g.out = d_x; g.ldo = d; g.R = d_x; g.tag = GEMV_FC2;
                 proj(g, 0);
             }
         }
         if (LR > 0) {
             GemvArgs g;  // final LN + tied-embedding logits, only for the rows that are sampled from
-            g.x = d_x; g.ldx = d; g.n = LR; g.W = m.tok_emb; g.N = nv; g.K = d;
+            g.x = d_x; g.ldx = d; g.n = LR; g.W = m.tok_emb; if (m.dec_fp8) { g.W8 = m.tok_emb8; g.w_scale = m.tok_emb_s; } g.N = nv; g.K = d;
             g.ln_w = m.dec_ln_w; g.ln_b = m.dec_ln_b; g.out = d_logits; g.ldo = nv; g.d_rows = d_blk->logit_rows;
             g.tag = GEMV_LOGITS;
             MW_CHECK(logits_tile_supported(g), "hub: logits projection shape");

@@ -208,7 +208,7 @@ struct Context {
 };
 
 // throws on failure
-std::unique_ptr<Context> create_context(const unsigned char *data, size_t size, int device, DType wt);
+std::unique_ptr<Context> create_context(const unsigned char *data, size_t size, int device, DType wt, bool fp8 = false);
 // another stream context on src's GPU that shares src's uploaded weights (throws on failure)
 std::unique_ptr<Context> create_shared_context(const Context &src);
 

@@ -165,6 +165,9 @@ struct GemvArgs {
     const int *d_rows = nullptr;  // optional row gather: use x row d_rows[i] for output row i
     // bf16 matrix-core tile kernels only (dec_tile.hip): activations already bf16 (residual classes) / bf16 output
     int x_bf16 = 0, out_bf16 = 0;
+    // fp8 mode, tile kernels of the batched step only: W again as OCP e4m3 bytes [N][K] + one power-of-two scale per row
+    const void *W8 = nullptr;
+    const float *w_scale = nullptr;
 };
 void launch_gemv(const GemvArgs &a, DType wt, hipStream_t st);
 

@@ -124,6 +124,42 @@ __global__ __launch_bounds__(256) void dequant_kernel(const unsigned char *__res
     }
 }
 
+// fp8 mode: one workgroup per output row.  scale = the power of two that brings the row's largest magnitude under 448 (the
+// e4m3 maximum); bytes = RNE conversion by the hardware (v_cvt_pk_fp8_f32, the inverse of the decode the kernels use);
+// the bf16 row is overwritten with byte x scale (exact: 4 significant bits times a power of two).
+__global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(bf16_t *__restrict__ w, unsigned char *__restrict__ w8,
+                                                                float *__restrict__ scale, int K) {
+    __shared__ float red[256];
+    bf16_t *row = w + (size_t)blockIdx.x * K;
+    unsigned char *row8 = w8 + (size_t)blockIdx.x * K;
+    float mx = 0.0f;
+    for (int k = threadIdx.x; k < K; k += 256) mx = fmaxf(mx, fabsf(__uint_as_float((unsigned)row[k] << 16)));
+    red[threadIdx.x] = mx;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    mx = red[0];
+    int e = 0;
+    if (mx > 0.0f) {
+        (void)frexpf(mx / 448.0f, &e);                       // mx / 448 = f x 2^e, f in [0.5, 1)
+        if (ldexpf(1.0f, e - 1) * 448.0f >= mx) e -= 1;      // exact power of two: the smaller exponent is enough
+    }
+    e = max(-100, min(100, e));
+    const float sc = ldexpf(1.0f, e), inv = ldexpf(1.0f, -e);
+    if (threadIdx.x == 0) scale[blockIdx.x] = sc;
+    for (int k = 2 * threadIdx.x; k < K; k += 512) {  // K is even (multiple of 32)
+        const float a = __uint_as_float((unsigned)row[k] << 16) * inv, b = __uint_as_float((unsigned)row[k + 1] << 16) * inv;
+        const int pk = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);  // bytes 0, 1 of the result
+        row8[k] = (unsigned char)(pk & 0xff);
+        row8[k + 1] = (unsigned char)((pk >> 8) & 0xff);
+        const auto back = __builtin_amdgcn_cvt_pk_f32_fp8(pk, false);
+        row[k] = (bf16_t)(__float_as_uint(back[0] * sc) >> 16);
+        row[k + 1] = (bf16_t)(__float_as_uint(back[1] * sc) >> 16);
+    }
+}
+
 struct Loader {
     Model &m;
     std::map<std::string, TensorRef> dir;
@@ -183,6 +219,13 @@ struct Loader {
         void *p = alloc(n * dtype_size(m.wt));
         put(name, n, p, m.wt, conv_ci);
         return p;
+    }
+    // fp8 mode: e4m3 copy + row scales of an uploaded bf16 matrix [N][K] (the bf16 copy becomes the dequantised values)
+    void quantize(void *w_bf16, size_t N, size_t K, unsigned char *&w8, float *&scale) {
+        w8 = (unsigned char *)alloc(N * K);
+        scale = (float *)alloc(N * 4);
+        hipLaunchKernelGGL(quantize_rows_fp8_kernel, dim3((unsigned)N), dim3(256), 0, st, (bf16_t *)w_bf16, w8, scale, (int)K);
+        MW_HIP(hipGetLastError());
     }
     float *vec(const std::string &name, size_t n) {
         float *p = (float *)alloc(n * 4);
@@ -282,7 +325,8 @@ void free_device_block(void *p) {
 }
 }  // namespace
 
-void load_model(Model &m, const unsigned char *data, size_t size, DType wt, hipStream_t st) {
+void load_model(Model &m, const unsigned char *data, size_t size, DType wt, hipStream_t st, bool fp8) {
+    if (fp8 && wt != DType::BF16) throw std::runtime_error("fp8 weights go with bf16 activations");
     Cursor c{data, data + size};
     if (c.rd<uint32_t>() != GGML_MAGIC) throw std::runtime_error("bad magic (not a ggml model file)");
     int32_t h[11];
@@ -370,6 +414,9 @@ void load_model(Model &m, const unsigned char *data, size_t size, DType wt, hipS
     size_t vec_elems = (size_t)hp.n_audio_ctx * d + (size_t)hp.n_text_ctx * d + 2 * d + Le * (2 * d + d + d + 4 * d + d + 4 * d) +
                        Ld * (3 * d + d + d + d + 4 * d + d + 6 * d + 2 * d) + 4 * d + 64;
     m.arena_size = mat_elems * ws + vec_elems * 4 + (64 + 16 * (Le + Ld)) * 256 + (1 << 20);
+    if (fp8)  // e4m3 copies + row scales of the decoder projections and the logits matrix
+        m.arena_size += Ld * 12 * d * d + (size_t)hp.n_vocab * d + (Ld * 12 * d + hp.n_vocab) * 4 + (4 + 12 * Ld) * 256;
+    m.dec_fp8 = fp8;
     MW_HIP(hipMalloc((void **)&m.arena, m.arena_size));
     m.arena_owner = std::shared_ptr<void>(m.arena, free_device_block);
     L.staging_size = max_bytes;
@@ -438,7 +485,16 @@ void load_model(Model &m, const unsigned char *data, size_t size, DType wt, hipS
             e.fc1_b = L.vec(p + "mlp.0.bias", 4 * d);
             e.fc2_w = L.mat(p + "mlp.2.weight", 4 * d * d);
             e.fc2_b = L.vec(p + "mlp.2.bias", d);
+            if (fp8) {
+                L.quantize(e.qkv_w, 3 * d, d, e.qkv_w8, e.qkv_s);
+                L.quantize(e.out_w, d, d, e.out_w8, e.out_s);
+                L.quantize(e.cq_w, d, d, e.cq_w8, e.cq_s);
+                L.quantize(e.co_w, d, d, e.co_w8, e.co_s);
+                L.quantize(e.fc1_w, 4 * d, d, e.fc1_w8, e.fc1_s);
+                L.quantize(e.fc2_w, d, 4 * d, e.fc2_w8, e.fc2_s);
+            }
         }
+        if (fp8) L.quantize(m.tok_emb, (size_t)hp.n_vocab, d, m.tok_emb8, m.tok_emb_s);
         m.dec_ln_w = L.vec("decoder.ln.weight", d);
         m.dec_ln_b = L.vec("decoder.ln.bias", d);
         MelTables tab;

@@ -67,6 +67,9 @@ struct DecLayer {
     float *fc1_b;
     void *fc2_w;
     float *fc2_b;
+    // fp8 mode (Model::dec_fp8): the same matrices as e4m3 bytes + one power-of-two scale per output row
+    unsigned char *qkv_w8 = nullptr, *out_w8 = nullptr, *cq_w8 = nullptr, *co_w8 = nullptr, *fc1_w8 = nullptr, *fc2_w8 = nullptr;
+    float *qkv_s = nullptr, *out_s = nullptr, *cq_s = nullptr, *co_s = nullptr, *fc1_s = nullptr, *fc2_s = nullptr;
 };
 
 struct Hub;  // engine.hpp: the per-GPU batcher of decode steps over the contexts that share these weights
@@ -90,6 +93,14 @@ struct Model {
     void *ckv_w = nullptr;   // [L][2][d][d]  cross-attention key | value weights of every decoder layer
     float *ckv_b = nullptr;  // [L][2][d]     (key halves zero)
     float *dec_ln_w = nullptr, *dec_ln_b = nullptr;
+    // fp8 weights (MW_PRECISION_FP8): every decoder projection and the logits matrix also live as OCP e4m3 bytes with one
+    // power-of-two fp32 scale per output row (scale = 2^ceil(log2(absmax / 448)), value = e4m3 x scale); the decode tile
+    // kernels stream those (half the bytes).  The bf16 copies are REPLACED by the dequantised values — exact in bf16 because
+    // the scale is a power of two — so prompt prefill (bf16 kernels) and the steps compute with one and the same model.
+    // The encoder keeps bf16 weights (its GEMMs are not bound by weight bytes).
+    bool dec_fp8 = false;
+    unsigned char *tok_emb8 = nullptr;
+    float *tok_emb_s = nullptr;
     // device arena
     char *arena = nullptr;
     size_t arena_size = 0, arena_used = 0;
@@ -103,6 +114,7 @@ struct Model {
 
 // Parses `size` bytes at `data` (a whole ggml-*.bin image) and uploads to the current HIP device.
 // Throws std::runtime_error on malformed input.
-void load_model(Model &m, const unsigned char *data, size_t size, DType wt, hipStream_t st);
+// fp8 = true (with wt = BF16): additionally quantise the decoder's matrices to e4m3 (Model::dec_fp8).
+void load_model(Model &m, const unsigned char *data, size_t size, DType wt, hipStream_t st, bool fp8 = false);
 
 }  // namespace mw

@@ -31,21 +31,22 @@ def big_model(tmp_path_factory):
     d = tmp_path_factory.mktemp("full_dims")
     cache = {}
 
-    def get(preset):
-        if preset not in cache:
-            path = str(d / f"ggml-{preset}-synth-s1234.bin")
-            synth_large.write_large(path, preset, seed=1234, quiet_special=True)
-            cache[preset] = path
-        return cache[preset]
+    def get(preset, fp8_decoder=False):
+        key = (preset, fp8_decoder)
+        if key not in cache:
+            path = str(d / f"ggml-{preset}-synth-s1234{'-e4m3' if fp8_decoder else ''}.bin")
+            synth_large.write_large(path, preset, seed=1234, quiet_special=True, fp8_decoder=fp8_decoder)
+            cache[key] = path
+        return cache[key]
 
     return get
 
 
-def _teacher_forced(pkg, path, n_rows=5, steps=8):
+def _teacher_forced(pkg, path, n_rows=5, steps=8, precision=None):
     pyoracle.lib().ow_set_threads(16)
     pcm = ggml_io.synth_pcm(100, 30.0)
     orc = pyoracle.Oracle(path)
-    eng = pkg.Engine(path, precision=pkg.PRECISION_BF16)
+    eng = pkg.Engine(path, precision=pkg.PRECISION_BF16 if precision is None else precision)
     try:
         orc.mel(pcm)
         eng.mel(pcm)
@@ -146,3 +147,50 @@ def test_turbo_dims_bf16_teacher_forced_and_8_shared_weight_contexts(pkg, big_mo
     finally:
         for e in engs[1:] + engs[:1]:
             e.close()
+
+
+def test_turbo_dims_fp8_weights_teacher_forced_and_bit_equal_to_bf16_on_the_same_weights(pkg, big_model):
+    """BASELINE configs[4] precision: decoder projections + logits matrix as e4m3 bytes with a power-of-two scale per row.
+    The file's decoder weights are written already rounded to that grid (tools/ggml_io.e4m3_quantize_dequantize_rows), so
+    the fp32 oracle, the bf16 engine and the fp8 engine all hold the SAME weights and the comparison isolates the kernels:
+      * against the oracle: the bf16 tolerances of the tests above, unchanged;
+      * against the bf16 engine: the logits are equal to the bit (e4m3 -> bf16 is exact, the scale is a power of two applied
+        to the finished fp32 sum) — every fp8 kernel variant (qkv, cross-q, fc1, attention outputs, fc2, logits; 1, 5 and 16
+        rows) is checked element by element this way.
+    On a file that is NOT pre-rounded the fp8 engine differs from the bf16 engine by the quantisation itself (printed)."""
+    path = big_model("large-v3-turbo", fp8_decoder=True)
+    _teacher_forced(pkg, path, n_rows=5, steps=8, precision=pkg.PRECISION_FP8)
+    pcm = ggml_io.synth_pcm(100, 30.0)
+
+    def run(p, precision):
+        eng = pkg.Engine(p, precision=precision)
+        try:
+            eng.mel(pcm)
+            eng.encode(0)
+            prompt = [eng.sot, eng.sot + 1, eng.L.whisper_token_transcribe(eng.ctx)]
+            out = []
+            for r in range(8):
+                out.append(eng.decode(prompt, 0, r))       # 3-row calls (5-row kernels)
+            out.append(eng.decode_rows([100 + r for r in range(8)], [3] * 8, list(range(8))))       # 8 rows -> 16-row kernels
+            out.append(eng.decode_rows([7], [4], [0]))                                              # 1-row kernels
+            out.append(eng.decode_rows([200 + r for r in range(5)], [4] * 5, [1, 2, 3, 4, 5]))      # 5-row kernels
+            out.append(eng.decode([eng.sot - 1 - r for r in range(12)], 5, 6))                      # 12-token call, 16-row kernels
+            eng.set_force_decode_steps(24)
+            par = eng.default_params(pkg.SAMPLING_BEAM_SEARCH, temperature_inc=0.0, duration_ms=30000, language="en")
+            assert eng.full(par, pcm) == 0
+            return out, eng.token_ids()
+        finally:
+            eng.close()
+
+    l8, t8 = run(path, pkg.PRECISION_FP8)
+    l16, t16 = run(path, pkg.PRECISION_BF16)
+    for a, b in zip(l8, l16):
+        assert np.isfinite(a).all() and np.array_equal(a, b)
+    assert t8 == t16 and len(t8) >= 1
+    # the price of the quantisation itself, on weights that are not on the e4m3 grid
+    raw = big_model("large-v3-turbo")
+    q8, _ = run(raw, pkg.PRECISION_FP8)
+    q16, _ = run(raw, pkg.PRECISION_BF16)
+    worst = max(float(np.abs(a - b).max() / (b.max() - b.min())) for a, b in zip(q8, q16))
+    print(f"e4m3 weights vs bf16 weights of an unrounded file: worst |d logits| / spread = {worst:.4f}")
+    assert worst < 0.25

@@ -352,6 +352,37 @@ def f16_round(t: Dict[str, np.ndarray], hp: HParams) -> Dict[str, np.ndarray]:
     return {k: (v.astype(np.float16).astype(np.float32) if k in mats else v) for k, v in t.items()}
 
 
+# --------------------------------------------------------------------------------------------
+# OCP e4m3 (fp8) with one power-of-two scale per row: the engine's MW_PRECISION_FP8 weight format
+# --------------------------------------------------------------------------------------------
+FP8_DECODER_SUFFIXES = (".attn.query.weight", ".attn.key.weight", ".attn.value.weight", ".attn.out.weight",
+                        ".cross_attn.query.weight", ".cross_attn.out.weight", ".mlp.0.weight", ".mlp.2.weight")
+
+
+def is_fp8_decoder_tensor(name: str) -> bool:
+    """The tensors MW_PRECISION_FP8 quantises: decoder projections + the (tied) token embedding; not the cross K/V weights."""
+    return name == "decoder.token_embedding.weight" or (name.startswith("decoder.blocks.") and name.endswith(FP8_DECODER_SUFFIXES))
+
+
+def e4m3_quantize_dequantize_rows(a: np.ndarray) -> np.ndarray:
+    """a [N][K] float32 -> the nearest values of the form e4m3 x 2^s(row) (round to nearest even, saturating at 448),
+    s(row) the smallest exponent with 448 x 2^s >= max |row|.  Idempotent; every result is exact in bf16 and f16."""
+    a = np.asarray(a, dtype=np.float64)
+    mx = np.abs(a).max(axis=1, keepdims=True)
+    with np.errstate(divide="ignore"):
+        e = np.where(mx > 0, np.ceil(np.log2(mx / 448.0)), 0.0)
+    e = np.where(448.0 * 2.0 ** (e - 1) >= mx, e - 1, e)       # guard the log2 rounding at exact powers of two
+    e = np.where(448.0 * 2.0 ** e < mx, e + 1, e)
+    y = a / 2.0 ** e
+    ay = np.abs(y)
+    with np.errstate(divide="ignore"):
+        ex = np.where(ay > 0, np.floor(np.log2(ay)), -6.0)
+    ex = np.maximum(ex, -6.0)                                   # below 2^-6: subnormals, fixed step 2^-9
+    step = 2.0 ** (ex - 3.0)
+    q = np.minimum(np.rint(ay / step) * step, 448.0)
+    return (np.sign(y) * q * 2.0 ** e).astype(np.float32)
+
+
 def make_model_file(path: str, preset: str = "micro.en", seed: int = 1234, ftype: int | None = None,
                     quiet_special: bool = False, **overrides) -> HParams:
     hp = HParams(**{**PRESETS[preset].__dict__, **overrides})

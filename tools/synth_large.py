@@ -14,7 +14,10 @@ import numpy as np
 from tools import ggml_io
 
 
-def write_large(path: str, preset: str = "large-v3", seed: int = 1234, quiet_special: bool = True) -> ggml_io.HParams:
+def write_large(path: str, preset: str = "large-v3", seed: int = 1234, quiet_special: bool = True,
+                fp8_decoder: bool = False) -> ggml_io.HParams:
+    """fp8_decoder: the tensors MW_PRECISION_FP8 quantises are written already rounded to e4m3 x 2^s(row), so that an fp32
+    reader of the file (the oracle) and the engine's fp8 mode hold exactly the same weights."""
     hp = ggml_io.PRESETS[preset]
     rng = np.random.default_rng(seed)
     tmp = path + ".tmp.%d" % os.getpid()
@@ -45,6 +48,8 @@ def write_large(path: str, preset: str = "large-v3", seed: int = 1234, quiet_spe
             else:
                 fan_in = int(np.prod(shape[1:]))
                 a = rng.standard_normal(n, dtype=np.float32) * np.float32(max(0.02, 1.0 / np.sqrt(fan_in)))
+            if fp8_decoder and ggml_io.is_fp8_decoder_tensor(name):
+                a = ggml_io.e4m3_quantize_dequantize_rows(a.reshape(shape[0], -1)).reshape(-1)
             use_f16 = hp.ftype == 1 and is_mat
             ne = list(reversed(shape))
             nb = name.encode()
