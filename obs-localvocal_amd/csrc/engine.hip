@@ -241,12 +241,24 @@ std::shared_ptr<Hub> create_hub(const Model &m, int device, bool use_graphs) {
 void Hub::submit_encode(EncRequest &r) {
     std::unique_lock<std::mutex> lk(mu_enc);
     queue_enc.push_back(&r);
+    if (busy_enc) cv_enc.notify_all();  // a leader may be collecting windows (below)
     while (!r.done) {
         if (busy_enc) {
             cv_enc.wait(lk);
             continue;
         }
         // idle: this thread leads the next pass over the oldest request and every later one with the same audio context
+        busy_enc = true;
+        if (r.peers > 1) {
+            // Other streams share these weights: their windows tend to arrive within microseconds of each other (workers woken
+            // by the same audio clock, threads released by the same finished pass), and a pass costs milliseconds — so the
+            // leader gives them 300 us to join before it starts (measured: 4 streams encoding in step formed passes of 2
+            // without this).  A context alone on its weights never waits.
+            const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(300);
+            const size_t want = (size_t)std::min(ENC_MAX_WINDOWS, r.peers);
+            while (queue_enc.size() < want && cv_enc.wait_until(lk, deadline) != std::cv_status::timeout) {
+            }
+        }
         std::vector<EncRequest *> batch;
         EncRequest *first = queue_enc.front();
         for (auto it = queue_enc.begin(); it != queue_enc.end();) {
@@ -257,7 +269,6 @@ void Hub::submit_encode(EncRequest &r) {
                 ++it;
             }
         }
-        busy_enc = true;
         lk.unlock();
         std::exception_ptr err;
         try {
@@ -708,6 +719,7 @@ void encode(Context &c, int seek) {
         r.c = &c;
         r.seek = seek;
         r.n_ctx = n_ctx;
+        r.peers = (int)c.model.hub.use_count();
         if (c.st_dirty) MW_HIP(hipEventRecord(c.ev_ready, c.st));
         c.model.hub->submit_encode(r);
         c.tm.n_encode++;

@@ -68,6 +68,7 @@ struct StepRequest {
 struct EncRequest {
     Context *c = nullptr;
     int seek = 0, n_ctx = 0;
+    int peers = 1;  // contexts attached to the same hub when the request was made (1: nobody to wait for)
     bool done = false;
     std::exception_ptr err;
 };

@@ -37,16 +37,45 @@ def main():
     from tools import ggml_io, synth_large
     model = sys.argv[1] if len(sys.argv) > 1 else "large-v3"
     iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+    windows = int(sys.argv[3]) if len(sys.argv) > 3 else 1   # > 1: that many contexts on one upload encode at the same time
     d = os.environ.get("MI355_WHISPER_BENCH_DIR", "/tmp/mi355_whisper_bench")
     os.makedirs(d, exist_ok=True)
     path = os.path.join(d, f"ggml-{model}-synth-s1234.bin")
     if not os.path.exists(path):
         synth_large.write_large(path, model, seed=1234, quiet_special=True)
     eng = pkg.Engine(path, precision=pkg.PRECISION_BF16)
-    eng.mel(ggml_io.synth_pcm(100, 30.0))
-    ms = C.c_float(0)
-    assert eng.L.mw_bench_encode(eng.ctx, iters, C.byref(ms)) == 0
-    print(f"encoder + cross-K/V of one 30 s window ({model}, bf16): {ms.value:.3f} ms per pass ({iters} passes)")
+    if windows <= 1:
+        eng.mel(ggml_io.synth_pcm(100, 30.0))
+        ms = C.c_float(0)
+        assert eng.L.mw_bench_encode(eng.ctx, iters, C.byref(ms)) == 0
+        print(f"encoder + cross-K/V of one 30 s window ({model}, bf16): {ms.value:.3f} ms per pass ({iters} passes)")
+    else:
+        # the windows of `windows` streams through the hub: their encode calls meet in one pass with M = windows x 1500
+        import threading
+        import time
+        engs = [eng] + [pkg.Engine(path, precision=pkg.PRECISION_BF16, share=eng) for _ in range(windows - 1)]
+        for i, e in enumerate(engs):
+            e.mel(ggml_io.synth_pcm(100 + i, 30.0))
+        gate = threading.Barrier(windows)
+
+        def work(e):
+            for _ in range(iters + 1):
+                gate.wait()
+                assert e.L.mw_encode(e.ctx, 0, 0) == 0
+
+        s0 = eng.hub_stats()
+        th = [threading.Thread(target=work, args=(e,)) for e in engs]
+        t0 = time.time()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        dt = time.time() - t0
+        s1 = eng.hub_stats()
+        print(f"{windows} windows at a time ({model}, bf16): {1000.0 * dt / (iters + 1) / windows:.3f} ms per window, "
+              f"{s1[4] - s0[4]} windows in {s1[3] - s0[3]} encoder passes")
+        for e in engs[1:]:
+            e.close()
     eng.close()
 
 

@@ -9,4 +9,9 @@ for r in csv.DictReader(open(sys.argv[1])):
     key = (n, r.get("Grid_Size_X","?"), r.get("Grid_Size_Y","?"), r.get("Grid_Size_Z","?"))
     agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in sorted(agg.items()):
-    print(k, {c: round(sum(v)/len(v)) for c, v in d.items()}, "n=", len(next(iter(d.values()))))
+    avg = {c: sum(v) / len(v) for c, v in d.items()}
+    util = ""
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in avg and avg.get("GRBM_GUI_ACTIVE", 0) > 0:
+        # busy cycles summed over the 1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs
+        util = " mfma_util=%5.1f%%" % (100.0 * avg["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * avg["GRBM_GUI_ACTIVE"] / 8.0))
+    print(k, "n=%d" % len(next(iter(d.values()))), util, {c: round(v) for c, v in avg.items()})
