@@ -6,7 +6,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(sys.argv[1])):
     n = re.sub(r"\(.*", "", r["Kernel_Name"].replace("mw::(anonymous namespace)::", "").replace("void ", ""))[:50]
     if "gemm" not in n and "flash" not in n: continue
-    key = (n, r.get("Grid_Size_X","?"), r.get("Grid_Size_Y","?"), r.get("Grid_Size_Z","?"))
+    key = (n, "threads=" + r.get("Grid_Size", "?"), "wg=" + r.get("Workgroup_Size", "?"))
     agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in sorted(agg.items()):
     avg = {c: sum(v) / len(v) for c, v in d.items()}
