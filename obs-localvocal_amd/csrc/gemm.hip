@@ -248,12 +248,68 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
     }
 }
 
-// epilogue shared by the bf16 kernels: one vector store of 4 consecutive output elements per MFMA tile and lane
+// epilogue shared by the bf16 kernels: one vector store of 4 consecutive output elements per MFMA tile and lane.
+// Its loads are vectors too: the bias of a lane's 4 columns is one 16-byte load per column tile (hoisted out of the row
+// tiles), the residual one 16-byte load per tile.  As 4 + 4 clamped dword loads per tile (64-128 tiles' worth of dword
+// loads per lane, issued by every wave of the CU at the same moment) they were what a tile spent its time on outside the
+// k-loop: ~20 us per round of 256 x 256 tiles, no matter whether anything was stored.
 template <typename TOUT, int BM, bool TR, int WJ>
 __device__ __forceinline__ void gemm_bf16_epilogue(const GemmArgs &a, f32x4 (&acc)[4][WJ], TOUT *C, const float *bias, const float *R,
                                                    int m0, int n0, int wr, int wc, int lane) {
     constexpr int WCOLS = BM == 128 ? 64 : 32;
     const int M = a.M, N = a.N;
+    if (!TR && a.epi_vec) {
+        // vector form (launch_gemm checked N % 4 == 0 and the 16-byte alignment of bias, residual and output rows): every
+        // load is unconditional — out-of-range lanes read a clamped address — because a branch around a load ends in a wait
+        // for ALL loads in flight at its join, the next tile's operand loads included; only the store is predicated
+        float bj[WJ][4];
+#pragma unroll
+        for (int j = 0; j < WJ; ++j) {
+            const int nb = min(n0 + wc * WCOLS + j * 16 + (lane >> 4) * 4, N - 4);
+            const float4 b4 = *reinterpret_cast<const float4 *>((bias ? bias : a.epi_zero) + (bias ? nb : 0));
+            bj[j][0] = b4.x; bj[j][1] = b4.y; bj[j][2] = b4.z; bj[j][3] = b4.w;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            // one row tile at a time: left alone the scheduler hoists every residual load of the epilogue to its top
+            __builtin_amdgcn_sched_barrier(0);
+            const int mb = m0 + wr * 64 + i * 16 + (lane & 15), mc = min(mb, M - 1);
+            float4 rv[WJ];
+#pragma unroll
+            for (int j = 0; j < WJ; ++j) {
+                const int nb = min(n0 + wc * WCOLS + j * 16 + (lane >> 4) * 4, N - 4);
+                rv[j] = R ? *reinterpret_cast<const float4 *>(R + (long)mc * a.ldr + nb) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+#pragma unroll
+            for (int j = 0; j < WJ; ++j) {
+                const int nb = n0 + wc * WCOLS + j * 16 + (lane >> 4) * 4;
+                const float rr[4] = {rv[j].x, rv[j].y, rv[j].z, rv[j].w};
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = acc[i][j][r] * a.alpha;
+                    if (bias) x += bj[j][r];
+                    if (a.act == ACT_GELU) x = gelu_fast(x);
+                    if (R) x += rr[r];
+                    v[r] = x;
+                }
+                TOUT *dst = C + (long)mc * a.ldc + min(nb, N - 4);
+                if (mb < M && nb < N) {
+                    if constexpr (sizeof(TOUT) == 4) {
+                        *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+                        __hip_bfloat16 h0 = __float2bfloat16(v[0]), h1 = __float2bfloat16(v[1]), h2 = __float2bfloat16(v[2]),
+                                       h3 = __float2bfloat16(v[3]);
+                        uint2 pk;
+                        pk.x = (unsigned)*reinterpret_cast<bf16_t *>(&h0) | ((unsigned)*reinterpret_cast<bf16_t *>(&h1) << 16);
+                        pk.y = (unsigned)*reinterpret_cast<bf16_t *>(&h2) | ((unsigned)*reinterpret_cast<bf16_t *>(&h3) << 16);
+                        *reinterpret_cast<uint2 *>(dst) = pk;
+                    }
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -518,6 +574,144 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GS == 1 ? 4
     gemm_bf16_epilogue<TOUT, BM, TR, WJ>(a, acc, C, bias, R, m0, n0, wr, wc, lane);
 }
 
+// ---- bf16 path for the many-window encoder pass: 256 x 256 tile, persistent workgroups ----
+// 8 waves as 2 (M) x 4 (N), each 128 x 64 of the output (acc = 128 registers): a k-step moves 64 KB for 8.4 MFLOP, twice the
+// flops per byte of the 128 x 128 tile, and a wave reads 24 fragments for 64 MFMAs instead of 16 for 32; the k-loop runs at
+// ~1.4 PFLOP/s (measured from two K extents of one grid).  LDS: two k-step buffers of four 16 KB half-tiles (A rows 0-127 |
+// A rows 128-255 | W rows 0-127 | W rows 128-255), the 128-byte swizzled rows and fragment reads of the kernels above,
+// filled by global_load_lds; the loads of step kt + 1 are issued behind the barrier of step kt (A before the first half of
+// the products, W before the second) and waited for at the top of step kt + 1.  One workgroup per CU.
+// With one workgroup per CU nothing hides a tile's prologue and epilogue (~20 us per round of tiles, as much as a K = 1280
+// k-loop): the workgroups are PERSISTENT — min(tiles, 256) of them, each walking tiles of an XCD-contiguous range — and the
+// first k-step of a workgroup's next tile is issued before the epilogue of the current one, so the stores of tile i and the
+// cold loads of tile i + 1 overlap.  No batch dimension; needs K % 64 == 0, N % 256 == 0; no transposed store.
+template <typename TOUT>
+__global__ __launch_bounds__(512) void gemm_bf16_256_kernel(GemmArgs a) {
+    constexpr int BK = 64, RB = 128, HALF = 128 * RB, STAGE = 4 * HALF;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 2, wc = wave & 3;
+    const bf16_t *A = (const bf16_t *)a.A, *W = (const bf16_t *)a.W;
+    TOUT *C = (TOUT *)a.C;
+    const int M = a.M, N = a.N, K = a.K;
+    const int tiles_n = N / 256, tiles_m = (M + 255) / 256, ntiles = tiles_m * tiles_n, per_xcd = (ntiles + 7) / 8;
+    auto swz8 = [](int r, int c) { return r * RB + ((c ^ (r & 7)) << 4); };
+    // tile of round r: workgroups that share an XCD (ids equal mod 8) walk one contiguous range of the tile order (N-tile
+    // fastest), so what an XCD's workgroups hold at one time is a compact block of A panels x all W panels
+    auto tile_of = [&](int r, int &m0, int &n0) -> bool {
+        const int L = blockIdx.x + r * gridDim.x, j = L >> 3, p = (L & 7) * per_xcd + j;
+        if (j >= per_xcd || p >= ntiles) return false;
+        m0 = (p / tiles_n) * 256;
+        n0 = (p % tiles_n) * 256;
+        return true;
+    };
+    // piece q of this wave in a half-tile: rows 8 * wave + 64 * q .. + 7; lane -> row lane >> 3, slot lane & 7, global chunk slot ^ (row & 7)
+    const bf16_t *ga[2][2], *gw[2][2];
+    auto point = [&](int m0, int n0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int row = 8 * wave + 64 * q + (lane >> 3), chk = (lane & 7) ^ (row & 7);
+                ga[h][q] = A + (long)min(m0 + 128 * h + row, M - 1) * a.lda + chk * 8;
+                gw[h][q] = W + (long)min(n0 + 128 * h + row, N - 1) * a.ldw + chk * 8;
+            }
+    };
+    const int nk = K / BK;
+    using gptr_t = const __attribute__((address_space(1))) void *;
+    using lptr_t = __attribute__((address_space(3))) void *;
+    auto issue_a = [&](int kt, int stage) {
+        const long off = (long)kt * BK;
+        unsigned char *sa = lds + stage * STAGE + (8 * wave) * RB;  // wave-uniform
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                __builtin_amdgcn_global_load_lds((gptr_t)(ga[h][q] + off), (lptr_t)(sa + h * HALF + 64 * q * RB), 16, 0, 0);
+    };
+    auto issue_w = [&](int kt, int stage) {
+        const long off = (long)kt * BK;
+        unsigned char *sw = lds + stage * STAGE + 2 * HALF + (8 * wave) * RB;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                __builtin_amdgcn_global_load_lds((gptr_t)(gw[h][q] + off), (lptr_t)(sw + h * HALF + 64 * q * RB), 16, 0, 0);
+    };
+    const int fr = lane & 15, fq = lane >> 4;
+    int m0 = 0, n0 = 0, round = 0;
+    bool have = tile_of(0, m0, n0);  // workgroup-uniform throughout
+    if (have) {
+        point(m0, n0);
+        issue_a(0, 0);
+        issue_w(0, 0);
+    }
+    int par = 0;  // LDS buffer of the step about to be multiplied (runs on across tiles)
+    while (have) {
+        f32x4 acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+        int m1 = 0, n1 = 0;
+        const bool have_next = tile_of(round + 1, m1, n1);
+        for (int kt = 0; kt < nk; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // this step is in LDS for every wave; every wave is done with the other buffer
+            const unsigned char *la = lds + par * STAGE + wr * HALF, *lw = lds + par * STAGE + (2 + (wc >> 1)) * HALF;
+            const int wcol = (wc & 1) * 64;
+            const bool last = kt + 1 == nk;
+            if (last && have_next) point(m1, n1);  // the loads below then fetch step 0 of the next tile
+            const bool more = !last || have_next;
+            const int nkt = last ? 0 : kt + 1;
+            if (more) issue_a(nkt, par ^ 1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 bfr[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8 *>(lw + swz8(wcol + j * 16 + fr, 4 * ks + fq));
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    bf16x8 af[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8 *>(la + swz8(hh * 64 + i * 16 + fr, 4 * ks + fq));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[hh * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                __builtin_bit_cast(bf16x8b, bfr[j]), __builtin_bit_cast(bf16x8b, af[i]), acc[hh * 4 + i][j], 0, 0, 0);
+                }
+                if (ks == 0 && more) issue_w(nkt, par ^ 1);
+            }
+            par ^= 1;
+        }
+        // epilogue of this tile while step 0 of the next one is in flight (it touches no LDS)
+        int m0e = m0, n0e = n0;
+        asm volatile("" : "+s"(m0e), "+s"(n0e));  // opaque: nothing of the epilogue (bias loads, addresses) is computed before the k-loop
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            f32x4(&part)[4][4] = *reinterpret_cast<f32x4(*)[4][4]>(&acc[hh * 4]);
+            gemm_bf16_epilogue<TOUT, 128, false, 4>(a, part, C, a.bias, a.R, m0e + wr * 128 + hh * 64, n0e + wc * 64, 0, 0, lane);
+        }
+        m0 = m1;
+        n0 = n1;
+        have = have_next;
+        ++round;
+    }
+}
+
+// 16 zero bytes in device memory: what the vector epilogue reads when a GEMM has no bias (an unconditional load)
+__device__ __attribute__((aligned(16))) float g_epi_zero[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+const float *epi_zero_device() {
+    thread_local const float *ptr[64] = {};
+    int dev = 0;
+    MW_HIP(hipGetDevice(&dev));
+    MW_CHECK(dev >= 0 && dev < 64, "gemm: device index");
+    if (!ptr[dev]) MW_HIP(hipGetSymbolAddress((void **)&ptr[dev], HIP_SYMBOL(g_epi_zero)));
+    return ptr[dev];
+}
+
 }  // namespace
 
 void launch_gemm(const GemmArgs &args, DType in, DType out, hipStream_t st) {
@@ -532,6 +726,14 @@ void launch_gemm(const GemmArgs &args, DType in, DType out, hipStream_t st) {
     // note: lda < K is legal — the conv stem passes overlapping row views (row t = rows t-1..t+1)
     MW_CHECK(a.nz0 >= 1 && a.nz1 >= 1 && (long)a.nz0 * a.nz1 <= 65535, "gemm: batch count");
     if (a.R) MW_CHECK(a.ldr > 0, "gemm: residual stride");
+    {   // vector epilogue (gemm_bf16_epilogue): 4 consecutive columns per lane as 16-byte loads / 8- or 16-byte stores
+        const size_t oa = out == DType::F32 ? 16 : 8, os = out == DType::F32 ? 4 : 2;
+        const auto al = [](const void *p, size_t n) { return ((uintptr_t)p % n) == 0; };
+        a.epi_vec = in == DType::BF16 && !a.trans_c && a.N % 4 == 0 && a.N >= 4 && al(a.C, oa) && a.ldc % 4 == 0 &&
+                    (a.sC0 * os) % oa == 0 && (a.sC1 * os) % oa == 0 && (!a.bias || (al(a.bias, 16) && a.sB0 % 4 == 0 && a.sB1 % 4 == 0)) &&
+                    (!a.R || (al(a.R, 16) && a.ldr % 4 == 0 && a.sR0 % 4 == 0 && a.sR1 % 4 == 0));
+        a.epi_zero = epi_zero_device();
+    }
     // 64-row tiles when 128-row tiles would give the 256 CUs at most about one tile each (N = d and N = 2d at M = 1500):
     // Q|K (240 tiles of 128 rows) 29.6 us, as 480 tiles of 64 rows 26.4; fc1 (480 tiles): 48 vs 56
     const long tiles128 = (long)ceil_div(a.N, BN) * ceil_div(a.M, 128) * a.nz0 * a.nz1;
@@ -539,8 +741,13 @@ void launch_gemm(const GemmArgs &args, DType in, DType out, hipStream_t st) {
     // many-tile grids (the encoder pass over the windows of several streams, M = windows x 1500): the single-stage LDS-direct
     // kernel, four workgroups per CU
     const bool many = in == DType::BF16 && !a.trans_c && a.K % 64 == 0 && a.K >= 256 && tiles128 >= 900;
-    const int bm = bm64 ? 64 : 128;
-    dim3 grid(ceil_div(a.N, BN), ceil_div(a.M, bm), a.nz0 * a.nz1);
+    // 256 x 256 persistent tiles once they fill the chip (>= 200 of them for 256 CUs): fc2 / attention output at M = 12000,
+    // Q|K and fc1 from M = 6000 on
+    const long tiles256 = (long)(a.N / 256) * ceil_div(a.M, 256);
+    const bool big = in == DType::BF16 && !a.trans_c && a.K % 64 == 0 && a.K >= 256 && a.N % 256 == 0 && a.nz0 * a.nz1 == 1 &&
+                     (a.glds == 8 || (a.glds == 0 && tiles256 >= 200));
+    const int bm = big ? 256 : bm64 ? 64 : 128, bn = big ? 256 : BN;
+    dim3 grid(ceil_div(a.N, bn), ceil_div(a.M, bm), a.nz0 * a.nz1);
     MW_CHECK(grid.y <= 65535, "gemm: M too large for grid.y");
     {   // XCD-aware tile order (xcd_tile_coord): super-row height for which an XCD's share of the tiles is a compact rectangle
         const long T = (long)grid.x * grid.y, G = T * grid.z, share = (G + 7) / 8;
@@ -550,7 +757,7 @@ void launch_gemm(const GemmArgs &args, DType in, DType out, hipStream_t st) {
                 a.hb = (int)grid.y;  // an XCD gets whole batch slices: any order inside a slice
             } else {
                 // rectangle of `share` tiles with equal operand bytes on both sides: h * BM = w * BN  ->  h = sqrt(share * BN / BM)
-                const double h = sqrt((double)share * BN / bm);
+                const double h = sqrt((double)share * bn / bm);
                 double best = 1e30;
                 for (int xm = 1; xm <= 8; xm *= 2) {
                     const int hb = ceil_div((int)grid.y, xm);
@@ -576,7 +783,12 @@ void launch_gemm(const GemmArgs &args, DType in, DType out, hipStream_t st) {
         if (a.trans_c) hipLaunchKernelGGL((gemm_bf16_glds_kernel<TOv, BMv, true, 4>), grid, dim3(256), 0, st, a);       \
         else hipLaunchKernelGGL((gemm_bf16_glds_kernel<TOv, BMv, false, 4>), grid, dim3(256), 0, st, a);                \
     } while (0)
-    if (many && out == DType::F32) {
+    if (big) {
+        // persistent: one workgroup per CU at most, a multiple of 8 so that every XCD's range is walked in step
+        const dim3 pgrid((unsigned)std::min<long>(ceil_div<long>((long)grid.x * grid.y, 8) * 8, 256));
+        if (out == DType::F32) hipLaunchKernelGGL((gemm_bf16_256_kernel<float>), pgrid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((gemm_bf16_256_kernel<bf16_t>), pgrid, dim3(512), 0, st, a);
+    } else if (many && out == DType::F32) {
         hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, 128, false, 1>), grid, dim3(256), 0, st, a);
     } else if (many) {
         hipLaunchKernelGGL((gemm_bf16_glds_kernel<bf16_t, 128, false, 1>), grid, dim3(256), 0, st, a);

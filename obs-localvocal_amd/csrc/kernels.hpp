@@ -68,6 +68,8 @@ struct GemmArgs {
     int act = ACT_NONE;
     int trans_c = 0;
     int hb = 0;  // set by launch_gemm: M-tiles per super-row of the XCD-aware tile order (0: tile = blockIdx)
+    int epi_vec = 0;                  // set by launch_gemm: shapes / alignment allow the vector epilogue
+    const float *epi_zero = nullptr;  // set by launch_gemm: 16 zero bytes on the device (bias stand-in)
     int glds = 0;  // bf16: stage operands with global_load_lds instead of the register ring (Context::gemm_glds)
 };
 // in: element type of A and W; out: element type of C

@@ -1,6 +1,6 @@
 // Development microbenchmark: the encoder's GEMM shapes through launch_gemm at M = windows x 1500 rows.
 //   make -C tools/microbench mb_gemm && ./mb_gemm [variant]
-#include "../../obs-localvocal_amd/csrc/kernels.hpp"
+#include "../../obs-localvocal_amd/csrc/gemm.hip"
 
 #include <cstdio>
 #include <cstdlib>
@@ -11,7 +11,7 @@ using namespace mw;
 int main(int argc, char **argv) {
     const int variant = argc > 1 ? atoi(argv[1]) : 0;
     const int d = 1280;
-    struct Shape { const char *name; int N, K; bool f32out, gelu, res; int probe = 0; };
+    struct Shape { const char *name; int N, K; bool f32out, gelu, res; };
     const Shape shapes[] = {{"qk", 2 * d, d, false, false, false}, {"out", d, d, true, false, true},
                             {"fc1", 4 * d, d, false, true, false}, {"fc2", d, 4 * d, true, false, true},
                             {"fc1n", 4 * d, d, false, false, false}, {"outn", d, d, true, false, false},
@@ -28,11 +28,36 @@ int main(int argc, char **argv) {
     MW_HIP(hipMemset(bias, 0, 4 * d * 4)); MW_HIP(hipMemset(C, 0, maxM * 4 * d * 4));
     hipStream_t st; MW_HIP(hipStreamCreate(&st));
     hipEvent_t e0, e1; MW_HIP(hipEventCreate(&e0)); MW_HIP(hipEventCreate(&e1));
+    // correctness of the variant against variant 0 (same k order: bit-identical), on the W = 1 shapes without residual aliasing
+    if (variant != 0) {
+        void *C0;
+        MW_HIP(hipMalloc(&C0, (size_t)1500 * 4 * d * 4));
+        for (const Shape &s : shapes) {
+            GemmArgs g;
+            g.A = A; g.lda = s.K; g.W = Wt; g.ldw = s.K; g.ldc = s.N; g.bias = bias;
+            g.M = 1500; g.N = s.N; g.K = s.K; g.act = s.gelu ? ACT_GELU : ACT_NONE;
+            const size_t bytes = (size_t)g.M * s.N * (s.f32out ? 4 : 2);
+            std::vector<unsigned char> h0(bytes), h1(bytes);
+            g.C = C0; g.glds = 0;
+            launch_gemm(g, DType::BF16, s.f32out ? DType::F32 : DType::BF16, st);
+            MW_HIP(hipStreamSynchronize(st));
+            MW_HIP(hipMemcpy(h0.data(), C0, bytes, hipMemcpyDeviceToHost));
+            MW_HIP(hipMemset(C0, 0xff, bytes));
+            g.glds = variant;
+            launch_gemm(g, DType::BF16, s.f32out ? DType::F32 : DType::BF16, st);
+            MW_HIP(hipStreamSynchronize(st));
+            MW_HIP(hipMemcpy(h1.data(), C0, bytes, hipMemcpyDeviceToHost));
+            size_t bad = 0;
+            for (size_t i = 0; i < bytes; ++i) bad += h0[i] != h1[i];
+            printf("check %-6s variant %d vs 0: %zu differing bytes of %zu\n", s.name, variant, bad, bytes);
+        }
+        MW_HIP(hipFree(C0));
+    }
     for (int W : Ws)
         for (const Shape &s : shapes) {
             GemmArgs g;
             g.A = A; g.lda = s.K; g.W = Wt; g.ldw = s.K; g.C = C; g.ldc = s.N; g.bias = bias;
-            g.M = W * 1500; g.N = s.N; g.K = s.K; g.act = s.probe ? s.probe : s.gelu ? ACT_GELU : ACT_NONE;
+            g.M = W * 1500; g.N = s.N; g.K = s.K; g.act = s.gelu ? ACT_GELU : ACT_NONE;
             if (s.res) { g.R = (float *)C; g.ldr = s.N; }
             g.glds = variant;
             const int it = 20;
