@@ -1001,13 +1001,16 @@ void launch_self_attn_batch(const float *q, const StepBlock *blk, long kv_layer_
 }
 
 void launch_cross_attn_batch(const float *q, const StepBlock *blk, long k_off, long v_off, float *partial, void *out,
-                             unsigned *head_cnt, int n_rows, int n_groups, int H, int d, int n_ctx_max, int splits, hipStream_t st) {
+                             unsigned *head_cnt, int n_rows, int max_group_rows, int n_groups, int H, int d, int n_ctx_max, int splits,
+                             hipStream_t st) {
     MW_CHECK(blk && n_rows >= 1 && n_rows <= STEP_MAX_ROWS && n_groups >= 1 && n_groups <= STEP_MAX_GROUPS && d == H * 64,
              "cross_attn_batch: shape");
     MW_CHECK(splits >= 1 && splits <= CROSS_SPLITS_MAX && ceil_div(n_ctx_max, splits) <= XK, "cross_attn_batch: at most 128 keys per split");
     const dim3 grid(n_groups * H * splits), block(MT);
-    // rows per request: <= 5 (beams of one stream) unless a prompt of up to 16 tokens rides in the step
-    if (n_rows <= 5)
+    // the kernel variant goes by the rows of ONE request (a workgroup serves one request): <= 5 (the beams of a stream, one
+    // row of a greedy stream) unless a prompt of up to 16 tokens rides in the step
+    MW_CHECK(max_group_rows >= 1 && max_group_rows <= n_rows, "cross_attn_batch: rows per request");
+    if (max_group_rows <= 5)
         hipLaunchKernelGGL((cross_attn_lean_kernel<5, bf16_t, true>), grid, block, 0, st, q, (const bf16_t *)nullptr, (const bf16_t *)nullptr,
                            blk->groups, k_off, v_off, partial, (bf16_t *)out, head_cnt, 0, H, d, 0, splits);
     else

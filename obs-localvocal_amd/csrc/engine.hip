@@ -390,12 +390,19 @@ void Hub::run_encode(const std::vector<EncRequest *> &batch) {
 void Hub::submit(StepRequest &r) {
     std::unique_lock<std::mutex> lk(mu);
     queue.push_back(&r);
+    auto idle_lane = [&]() -> Lane * {
+        for (int li = 0; li < n_lanes; ++li)
+            if (!lanes[li].busy) return &lanes[li];
+        return nullptr;
+    };
     while (!r.done) {
-        Lane *lane = nullptr;
-        for (int li = 0; li < n_lanes && !lane; ++li)
-            if (!lanes[li].busy) lane = &lanes[li];
-        if (!lane || r.taken) {  // every lane is busy, or this request is already part of a running step
-            cv.wait(lk);
+        Lane *lane = r.taken ? nullptr : idle_lane();
+        if (!lane) {
+            // every lane is busy, or this request is already part of a running step: sleep on the REQUEST's condition variable.
+            // Wake-ups are targeted (the requests of a finished step; the owner of the oldest queued request when a lane is
+            // free): with one shared condition variable every step woke all ~60 waiting threads of a 64-stream load, and the
+            // hand-over of the mutex among them delayed the next leader by more than the step itself took.
+            r.cv.wait(lk);
             continue;
         }
         // a lane is idle: this thread leads the next step on it.  It takes the oldest request and every later one that can
@@ -421,6 +428,7 @@ void Hub::submit(StepRequest &r) {
             }
         }
         lane->busy = true;
+        if (!queue.empty() && idle_lane()) queue.front()->cv.notify_one();  // more work and another lane free: next leader
         lk.unlock();
         std::exception_ptr err;
         try {
@@ -433,12 +441,15 @@ void Hub::submit(StepRequest &r) {
         for (StepRequest *q : batch) {
             q->err = err;
             q->done = true;
+            if (q != &r) q->cv.notify_one();
         }
         n_steps += 1;
         n_rows += (unsigned long long)rows;
         n_requests += batch.size();
         lane->busy = false;
-        cv.notify_all();
+        // the lane is free again: unless this thread leads the next step itself (its own request is still queued), hand the
+        // lead to the owner of the oldest queued request
+        if (!queue.empty() && (r.done || r.taken)) queue.front()->cv.notify_one();
     }
     lk.unlock();
     if (r.err) std::rethrow_exception(r.err);
@@ -459,7 +470,7 @@ void Hub::run(Lane &ln, const std::vector<StepRequest *> &batch) {
     const HParams &hp = m.hp;
     const int d = hp.n_text_state, H = hp.n_text_head, TC = hp.n_text_ctx, T = hp.n_audio_ctx, nv = hp.n_vocab;
     StepBlock &B = *h_blk;
-    int R = 0, G = 0, LR = 0, SR = 0, n_ctx_max = 1;
+    int R = 0, G = 0, LR = 0, SR = 0, n_ctx_max = 1, g_rows_max = 1;  // g_rows_max: most rows of one request (cross-attention variant)
     Context *lead = batch[0]->c;
     const bool sample = batch[0]->sample;
     for (StepRequest *q : batch) {
@@ -482,6 +493,7 @@ void Hub::run(Lane &ln, const std::vector<StepRequest *> &batch) {
         g.pad = 0;
         c.reorder_pending = false;
         n_ctx_max = std::max(n_ctx_max, c.n_ctx_cur);
+        g_rows_max = std::max(g_rows_max, q->n);
         for (int i = 0; i < q->n; ++i) {
             StepRow &r = B.rows[R + i];
             r.kself = (bf16_t *)c.d_kself;
@@ -562,10 +574,10 @@ void Hub::run(Lane &ln, const std::vector<StepRequest *> &batch) {
             }
             const long k_off = (long)l * 2 * T * d, v_off = k_off + (long)T * d;
             bracket(GEMV_N_TAGS + 1, [&]() {
-                launch_cross_attn_batch(d_q, d_blk, k_off, v_off, d_part, d_attd, d_head_cnt, R, G, H, d, n_ctx_max, splits, st);
+                launch_cross_attn_batch(d_q, d_blk, k_off, v_off, d_part, d_attd, d_head_cnt, R, g_rows_max, G, H, d, n_ctx_max, splits, st);
             });
             if (dup_tag == GEMV_N_TAGS + 1 && prof_tag < 0)
-                launch_cross_attn_batch(d_q, d_blk, k_off, v_off, d_part, d_attd, d_head_cnt, R, G, H, d, n_ctx_max, splits, st);
+                launch_cross_attn_batch(d_q, d_blk, k_off, v_off, d_part, d_attd, d_head_cnt, R, g_rows_max, G, H, d, n_ctx_max, splits, st);
             {
                 GemvArgs g;
                 g.x = (const float *)d_attd; g.x_bf16 = 1; g.ldx = d; g.n = R; g.W = e.co_w; if (m.dec_fp8) { g.W8 = e.co_w8; g.w_scale = e.co_s; } g.bias = e.co_b; g.N = d; g.K = d;
@@ -601,7 +613,7 @@ void Hub::run(Lane &ln, const std::vector<StepRequest *> &batch) {
         enqueue();
     } else {
         uint64_t key = (uint64_t)R | ((uint64_t)G << 8) | ((uint64_t)LR << 16) | ((uint64_t)SR << 24) | ((uint64_t)splits << 32) |
-                       ((uint64_t)(dup_tag + 1) << 40) | ((uint64_t)(sample ? 1 : 0) << 48);
+                       ((uint64_t)(dup_tag + 1) << 40) | ((uint64_t)(sample ? 1 : 0) << 48) | ((uint64_t)(g_rows_max > 5 ? 1 : 0) << 49);
         if (sample) {  // the rules' parameters are kernel arguments of the captured nodes: part of the key (FNV-1a over their bytes)
             uint64_t h = 1469598103934665603ull;
             for (size_t i = 0; i < sizeof(lp); ++i) h = (h ^ ((const unsigned char *)&lp)[i]) * 1099511628211ull;

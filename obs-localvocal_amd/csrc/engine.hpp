@@ -59,6 +59,7 @@ struct StepRequest {
     bool keep_logits = false;  // copy the request's logits rows into c->d_logits (stage calls, language detection, unfused sampler)
     bool solo = false;         // measurement hooks armed on the context: never batched with other requests
     std::string rules_key;     // requests share a step only when their rules + sampler parameters are identical
+    std::condition_variable cv;  // the owner sleeps here until its step is done or it is its turn to lead
     bool taken = false;        // part of a step that is running on some lane
     bool done = false;
     std::exception_ptr err;
@@ -106,7 +107,6 @@ struct Hub {
     int n_lanes = N_LANES;  // lanes in use (MI355_WHISPER_LANES, read when the hub is created)
     bool use_graphs = true;
     std::mutex mu;
-    std::condition_variable cv;
     std::deque<StepRequest *> queue;
     // statistics (mw_hub_stats)
     unsigned long long n_steps = 0, n_rows = 0, n_requests = 0, n_enc_passes = 0, n_enc_windows = 0;

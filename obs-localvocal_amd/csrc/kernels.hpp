@@ -215,7 +215,8 @@ void launch_self_attn_batch(const float *q, const StepBlock *blk, long kv_layer_
 // cross-attention of every request's rows over its own context's K / V (element offsets of the layer's K and V inside
 // a context's cross buffer); head_cnt: n_groups * H zeroed counters, left zeroed
 void launch_cross_attn_batch(const float *q, const StepBlock *blk, long k_off, long v_off, float *partial, void *out,
-                             unsigned *head_cnt, int n_rows, int n_groups, int H, int d, int n_ctx_max, int splits, hipStream_t st);
+                             unsigned *head_cnt, int n_rows, int max_group_rows, int n_groups, int H, int d, int n_ctx_max, int splits,
+                             hipStream_t st);
 bool logits_tile_supported(const GemvArgs &a);
 void launch_logits_tile(const GemvArgs &a, hipStream_t st);
 void launch_self_attn_wg(const float *q, const void *kcache, const void *vcache, const int *d_slot, const int *d_pos,
