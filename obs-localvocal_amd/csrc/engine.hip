@@ -169,7 +169,8 @@ Hub::~Hub() {
     (void)hipSetDevice(device);
     for (Lane &ln : lanes)
         if (ln.st) (void)hipStreamSynchronize(ln.st);
-    if (st_enc) (void)hipStreamSynchronize(st_enc);
+    for (EncLane &el : enc_lanes)
+        if (el.st) (void)hipStreamSynchronize(el.st);
     for (Lane &ln : lanes) {
         void *ptrs[] = {ln.d_blk, ln.d_x, ln.d_q, ln.d_part, ln.d_logits, ln.d_work, ln.d_attd, ln.d_ffd, ln.d_head_cnt, ln.d_suppress};
         for (void *p : ptrs)
@@ -179,10 +180,12 @@ Hub::~Hub() {
         for (auto &kv : ln.graphs) (void)hipGraphExecDestroy(kv.second);
         if (ln.st) (void)hipStreamDestroy(ln.st);
     }
-    void *ptrs[] = {e_conv_in, e_x1, e_h, e_qk, e_vt, e_att, e_ff, e_x};
-    for (void *p : ptrs)
-        if (p) (void)hipFree(p);
-    if (st_enc) (void)hipStreamDestroy(st_enc);
+    for (EncLane &el : enc_lanes) {
+        void *ptrs[] = {el.e_conv_in, el.e_x1, el.e_h, el.e_qk, el.e_vt, el.e_att, el.e_ff, el.e_x};
+        for (void *p : ptrs)
+            if (p) (void)hipFree(p);
+        if (el.st) (void)hipStreamDestroy(el.st);
+    }
 }
 
 std::shared_ptr<Hub> create_hub(const Model &m, int device, bool use_graphs) {
@@ -219,20 +222,20 @@ std::shared_ptr<Hub> create_hub(const Model &m, int device, bool use_graphs) {
         dev_alloc(ln.d_head_cnt, (size_t)STEP_MAX_GROUPS * 64);
         MW_HIP(hipMemsetAsync(ln.d_head_cnt, 0, (size_t)STEP_MAX_GROUPS * 64 * sizeof(unsigned), ln.st));
     }
-    {   // encoder workspace for ENC_MAX_WINDOWS windows (slabs back to back)
+    for (Hub::EncLane &el : h->enc_lanes) {  // encoder workspace for ENC_MAX_WINDOWS windows per lane (slabs back to back)
         const size_t W = Hub::ENC_MAX_WINDOWS, da = hp.n_audio_state, T = hp.n_audio_ctx, tp = (T + 63) / 64 * 64;
-        MW_HIP(hipStreamCreateWithFlags(&h->st_enc, hipStreamNonBlocking));
-        dev_alloc_bytes(h->e_conv_in, W * (2 * T + 2) * hp.n_mels * 2);
-        dev_alloc_bytes(h->e_x1, W * (2 * T + 1) * da * 2);
-        dev_alloc(h->e_x, W * T * da);
-        dev_alloc_bytes(h->e_h, W * T * da * 2);
-        dev_alloc_bytes(h->e_qk, W * T * 2 * da * 2);
-        dev_alloc_bytes(h->e_vt, W * da * tp * 2);
-        dev_alloc_bytes(h->e_att, W * T * da * 2);
-        dev_alloc_bytes(h->e_ff, W * T * 4 * da * 2);
-        MW_HIP(hipMemsetAsync(h->e_x1, 0, W * (2 * T + 1) * da * 2, h->st_enc));  // row 0 of every window is conv2's left zero pad
-        MW_HIP(hipMemsetAsync(h->e_vt, 0, W * da * tp * 2, h->st_enc));           // pad columns stay zero
-        MW_HIP(hipStreamSynchronize(h->st_enc));
+        MW_HIP(hipStreamCreateWithFlags(&el.st, hipStreamNonBlocking));
+        dev_alloc_bytes(el.e_conv_in, W * (2 * T + 2) * hp.n_mels * 2);
+        dev_alloc_bytes(el.e_x1, W * (2 * T + 1) * da * 2);
+        dev_alloc(el.e_x, W * T * da);
+        dev_alloc_bytes(el.e_h, W * T * da * 2);
+        dev_alloc_bytes(el.e_qk, W * T * 2 * da * 2);
+        dev_alloc_bytes(el.e_vt, W * da * tp * 2);
+        dev_alloc_bytes(el.e_att, W * T * da * 2);
+        dev_alloc_bytes(el.e_ff, W * T * 4 * da * 2);
+        MW_HIP(hipMemsetAsync(el.e_x1, 0, W * (2 * T + 1) * da * 2, el.st));  // row 0 of every window is conv2's left zero pad
+        MW_HIP(hipMemsetAsync(el.e_vt, 0, W * da * tp * 2, el.st));           // pad columns stay zero
+        MW_HIP(hipStreamSynchronize(el.st));
     }
     for (int li = 0; li < h->n_lanes; ++li) MW_HIP(hipStreamSynchronize(h->lanes[li].st));
     return h;
@@ -241,14 +244,21 @@ std::shared_ptr<Hub> create_hub(const Model &m, int device, bool use_graphs) {
 void Hub::submit_encode(EncRequest &r) {
     std::unique_lock<std::mutex> lk(mu_enc);
     queue_enc.push_back(&r);
-    if (busy_enc) cv_enc.notify_all();  // a leader may be collecting windows (below)
+    if (collecting) cv_enc.notify_all();  // a leader is gathering windows (below)
+    auto idle_lane = [&]() -> EncLane * {
+        for (EncLane &el : enc_lanes)
+            if (!el.busy) return &el;
+        return nullptr;
+    };
     while (!r.done) {
-        if (busy_enc) {
+        EncLane *lane = (r.taken || collecting) ? nullptr : idle_lane();
+        if (!lane) {
             cv_enc.wait(lk);
             continue;
         }
-        // idle: this thread leads the next pass over the oldest request and every later one with the same audio context
-        busy_enc = true;
+        // a lane is idle and nobody is gathering: this thread leads the next pass over the oldest request and every later one
+        // with the same audio context
+        collecting = true;
         if (r.peers > 1) {
             // Other streams share these weights: their windows tend to arrive within microseconds of each other (workers woken
             // by the same audio clock, threads released by the same finished pass), and a pass costs milliseconds — so the
@@ -263,19 +273,23 @@ void Hub::submit_encode(EncRequest &r) {
         EncRequest *first = queue_enc.front();
         for (auto it = queue_enc.begin(); it != queue_enc.end();) {
             if ((int)batch.size() < ENC_MAX_WINDOWS && (*it)->n_ctx == first->n_ctx) {
+                (*it)->taken = true;
                 batch.push_back(*it);
                 it = queue_enc.erase(it);
             } else {
                 ++it;
             }
         }
+        lane->busy = true;
+        collecting = false;
+        if (!queue_enc.empty()) cv_enc.notify_all();  // more windows queued: somebody leads them on the other lane
         lk.unlock();
         std::exception_ptr err;
         try {
-            run_encode(batch);
+            run_encode(*lane, batch);
         } catch (...) {
             err = std::current_exception();
-            (void)hipStreamSynchronize(st_enc);
+            (void)hipStreamSynchronize(lane->st);
         }
         lk.lock();
         for (EncRequest *q : batch) {
@@ -284,7 +298,7 @@ void Hub::submit_encode(EncRequest &r) {
         }
         n_enc_passes += 1;
         n_enc_windows += batch.size();
-        busy_enc = false;
+        lane->busy = false;
         cv_enc.notify_all();
     }
     lk.unlock();
@@ -293,15 +307,18 @@ void Hub::submit_encode(EncRequest &r) {
 
 // Encoder + cross-K/V (A.3) of W windows in one pass: the conv stem and the attention are batched over the windows, every
 // projection and LayerNorm of the transformer blocks runs over all W x n_ctx rows at once.
-void Hub::run_encode(const std::vector<EncRequest *> &batch) {
+void Hub::run_encode(EncLane &ln, const std::vector<EncRequest *> &batch) {
     MW_HIP(hipSetDevice(device));
+    void *const e_conv_in = ln.e_conv_in, *const e_x1 = ln.e_x1, *const e_h = ln.e_h, *const e_qk = ln.e_qk, *const e_vt = ln.e_vt,
+                *const e_att = ln.e_att, *const e_ff = ln.e_ff;
+    float *const e_x = ln.e_x;
     const HParams &hp = m.hp;
     const DType wt = DType::BF16;
     const size_t ws = 2;
     const int W = (int)batch.size(), n_ctx = batch[0]->n_ctx;
     const int d = hp.n_audio_state, H = hp.n_audio_head, n_mel = hp.n_mels, T2 = 2 * n_ctx;
     const int tp = (n_ctx + 63) / 64 * 64;
-    hipStream_t s = st_enc;
+    hipStream_t s = ln.st;
     const long cin_w = (long)(T2 + 2) * n_mel, x1_w = (long)(T2 + 1) * d;  // per-window slab sizes (elements)
     for (int w = 0; w < W; ++w) {
         Context &c = *batch[w]->c;

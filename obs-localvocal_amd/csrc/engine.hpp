@@ -70,6 +70,7 @@ struct EncRequest {
     Context *c = nullptr;
     int seek = 0, n_ctx = 0;
     int peers = 1;  // contexts attached to the same hub when the request was made (1: nobody to wait for)
+    bool taken = false;  // part of a pass that is running on some encoder lane
     bool done = false;
     std::exception_ptr err;
 };
@@ -114,20 +115,28 @@ struct Hub {
     // ENC_MAX_WINDOWS streams run as ONE pass with M = windows x n_ctx rows in every projection (more tiles per launch,
     // one pass over the encoder weights); each window's cross K / V goes to its own context
     static constexpr int ENC_MAX_WINDOWS = 8;
-    hipStream_t st_enc = nullptr;
-    void *e_conv_in = nullptr, *e_x1 = nullptr, *e_h = nullptr, *e_qk = nullptr, *e_vt = nullptr, *e_att = nullptr, *e_ff = nullptr;
-    float *e_x = nullptr;
+    // ONE encoder lane (stream + workspace).  Two were measured: encoder passes alone 3.88 -> 3.75 ms per window (the second pass
+    // fills the LayerNorm / V-projection / tail gaps of the first), but 64 streams with their decode steps beside them
+    // 5 985 -> 5 650 audio-s/s: two chip-filling GEMMs at a time leave the latency-bound step kernels even fewer CUs.
+    static constexpr int N_ENC_LANES = 1;
+    struct EncLane {
+        hipStream_t st = nullptr;
+        void *e_conv_in = nullptr, *e_x1 = nullptr, *e_h = nullptr, *e_qk = nullptr, *e_vt = nullptr, *e_att = nullptr, *e_ff = nullptr;
+        float *e_x = nullptr;
+        bool busy = false;
+    };
+    EncLane enc_lanes[N_ENC_LANES];
     std::mutex mu_enc;
     std::condition_variable cv_enc;
     std::deque<EncRequest *> queue_enc;
-    bool busy_enc = false;
+    bool collecting = false;  // a leader is gathering the windows of the next pass
 
     ~Hub();
     void submit(StepRequest &r);  // blocks until the request's step has run; rethrows its error
     void submit_encode(EncRequest &r);  // blocks until the window is encoded and its cross K / V are in the context
   private:
     void run(Lane &ln, const std::vector<StepRequest *> &batch);
-    void run_encode(const std::vector<EncRequest *> &batch);
+    void run_encode(EncLane &ln, const std::vector<EncRequest *> &batch);
 };
 std::shared_ptr<Hub> create_hub(const Model &m, int device, bool use_graphs);
 
