@@ -30,12 +30,12 @@ constexpr int FQ = 128;      // queries per workgroup
 constexpr int FK = 64;       // keys per step
 constexpr int FLD = 64 + 8;  // LDS row stride (elements): conflict-free 16-byte fragment reads
 
+using bf16x2b = __attribute__((ext_vector_type(2))) __bf16;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
-    // round to nearest even, like the conversions of the unfused path
-    unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
-    ua += 0x7fffu + ((ua >> 16) & 1u);
-    ub += 0x7fffu + ((ub >> 16) & 1u);
-    return (ua >> 16) | (ub & 0xffff0000u);
+    // round to nearest even, like the conversions of the unfused path: one v_cvt_pk_bf16_f32 (as integer arithmetic the
+    // pair cost seven VALU instructions, 112 per key step — the kernel is bound by its softmax VALU work, not by the MFMAs)
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2b));
 }
 
 __global__ __launch_bounds__(256) void enc_flash_attn_kernel(const bf16_t *__restrict__ qk, const bf16_t *__restrict__ vt,
@@ -109,38 +109,49 @@ __global__ __launch_bounds__(256) void enc_flash_attn_kernel(const bf16_t *__res
             }
         }
         // ---- online softmax (base 2), probabilities as P^T fragments ----
+        // VALU diet (the MFMAs of a key step take 512 cycles, the softmax took three times that): the running maximum is
+        // kept on the RAW scores and the scale rides in the exponent's fma; keys beyond n_ctx exist only in the last step;
+        // the accumulators are rescaled only when some query's maximum moved (corr is exactly 1 otherwise).
         uint4 pb[2][2];
         const int key_base = step * FK + 4 * fq;
+        const bool tail = step == nsteps - 1;  // wave-uniform
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
+            if (tail) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (key_base + 16 * t + r >= n_ctx) sa[i][t][r] = -INFINITY;
+            }
             float mx = m[i];
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = sa[i][t][r] * scale_log2;
-                    if (key_base + 16 * t + r >= n_ctx) v = -INFINITY;
-                    sa[i][t][r] = v;
-                    mx = fmaxf(mx, v);
-                }
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sa[i][t][r]);
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float corr = __builtin_amdgcn_exp2f(m[i] - mx);  // first step: exp2(-inf) = 0
-            m[i] = mx;
+            const bool moved = __builtin_amdgcn_ballot_w64(mx > m[i]) != 0;  // wave-uniform
+            const float nms = -mx * scale_log2;
             float ps = 0.0f;
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(sa[i][t][r] - mx);
+                    const float p = __builtin_amdgcn_exp2f(fmaf(sa[i][t][r], scale_log2, nms));
                     sa[i][t][r] = p;
                     ps += p;
                 }
-            l[i] = l[i] * corr + ps;  // this lane's share (its 16 keys of the step); completed across g at the end
+            if (moved) {
+                const float corr = __builtin_amdgcn_exp2f((m[i] - mx) * scale_log2);  // first step: exp2(-inf) = 0
+                m[i] = mx;
+                l[i] *= corr;
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+                for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[i][t][r] *= corr;
+                    for (int r = 0; r < 4; ++r) o[i][t][r] *= corr;
+            }
+            l[i] += ps;  // this lane's share (its 16 keys of the step); completed across g at the end
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 pb[i][c].x = pack_bf16(sa[i][2 * c][0], sa[i][2 * c][1]);
