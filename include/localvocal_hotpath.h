@@ -138,6 +138,17 @@ int lv_filter_update_model(lv_filter *f);
 /* the catalogue update_whisper_model looks names up in (models_info() + find_model_bin_file, model-downloader.h):
    name -> file on disk; file NULL or "" = listed but not downloaded (the download dialog is outside this library) */
 int lv_filter_register_model(lv_filter *f, const char *name, const char *file);
+/* The catalogue itself: load_models_info + find_model_bin_file (model-infos.cpp:114-260,
+   model-downloader.cpp:9-89) over a models_directory.json on disk (the reference tries GitHub first; no network here):
+   every MODEL_TYPE_TRANSCRIPTION entry is registered under its friendly name with the first *.bin found in
+   <data_models_dir>/<local_folder_name> or, failing that, <config_models_dir>/<local_folder_name> ("" = not on disk).
+   Returns the number of transcription models, < 0 on errors (unreadable file, malformed JSON). */
+int lv_filter_load_catalogue(lv_filter *f, const char *json_path, const char *data_models_dir, const char *config_models_dir);
+/* The check the catalogue's "sha256" field is there for; the reference parses the field and never compares it (no
+   counterpart).  0: the registered file's SHA-256 equals the catalogue's; 1: it differs; 2: model not in the catalogue,
+   not on disk, or listed without a digest; < 0: errors. */
+int lv_filter_verify_model(lv_filter *f, const char *friendly_name);
+int lv_model_file_sha256(const char *path, char *out_hex, size_t n); /* lower-case hex, n >= 65 */
 /* gf->whisper_model_path, gf->whisper_model_file_currently_loaded, gf->whisper_model_loaded_new, whisper_thread.joinable(),
    gf->enable_token_ts_dtw — for lifecycle tests and harnesses; any pointer may be NULL */
 int lv_filter_model_state(lv_filter *f, char *model_path, size_t n_path, char *file_loaded, size_t n_file, int *loaded_new,

@@ -116,6 +116,7 @@ EXPORTED_SYMBOLS = [
     "lv_filter_set_callbacks", "lv_filter_filter_audio", "lv_filter_push_packet", "lv_filter_clear_buffers",
     "lv_filter_input_bytes", "lv_filter_whisper_bytes", "lv_filter_segmentation_step", "lv_filter_reset_vad_state",
     "lv_filter_start", "lv_filter_stop", "lv_filter_update_model", "lv_filter_register_model", "lv_filter_model_state",
+    "lv_filter_load_catalogue", "lv_filter_verify_model", "lv_model_file_sha256",
     "lv_vad_speech_timestamps", "lv_remove_leading_trailing_nonalpha",
     "lv_resample",
 ]
@@ -263,6 +264,9 @@ def lib():
     L.lv_filter_start.argtypes = [P, C.c_char_p]
     L.lv_filter_stop.argtypes = [P]
     L.lv_filter_update_model.argtypes = [P]
+    L.lv_filter_load_catalogue.argtypes = [P, C.c_char_p, C.c_char_p, C.c_char_p]
+    L.lv_filter_verify_model.argtypes = [P, C.c_char_p]
+    L.lv_model_file_sha256.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
     L.lv_filter_register_model.argtypes = [P, C.c_char_p, C.c_char_p]
     L.lv_filter_model_state.argtypes = [P, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                         C.POINTER(C.c_int)]
@@ -565,6 +569,15 @@ class Filter:
         """models_info() entry + find_model_bin_file result for update_model (None: listed, not on disk)."""
         return self.L.lv_filter_register_model(self.f, name.encode(), file.encode() if file else None)
 
+    def load_catalogue(self, json_path: str, data_models_dir: str | None = None, config_models_dir: str | None = None) -> int:
+        """load_models_info + find_model_bin_file over a models_directory.json: registers every transcription model."""
+        enc = lambda v: v.encode() if v else None  # noqa: E731
+        return self.L.lv_filter_load_catalogue(self.f, json_path.encode(), enc(data_models_dir), enc(config_models_dir))
+
+    def verify_model(self, friendly_name: str) -> int:
+        """0: the file on disk has the catalogue's sha256; 1: it differs; 2: nothing to compare."""
+        return self.L.lv_filter_verify_model(self.f, friendly_name.encode())
+
     def update_model(self) -> int:
         """update_whisper_model(gf): 0 = a context is loaded afterwards, 1 = the filter is left stopped."""
         return self.L.lv_filter_update_model(self.f)
@@ -577,6 +590,13 @@ class Filter:
             raise RuntimeError("lv_filter_model_state failed")
         return dict(model_path=a.value.decode(), file_loaded=b.value.decode(), loaded_new=bool(new.value),
                     worker_running=bool(run.value), dtw=bool(dtw.value), context=bool(self.L.lv_filter_context(self.f)))
+
+
+def model_file_sha256(path: str) -> str:
+    buf = C.create_string_buffer(80)
+    if lib().lv_model_file_sha256(path.encode(), buf, len(buf)) != 0:
+        raise RuntimeError("lv_model_file_sha256 failed")
+    return buf.value.decode()
 
 
 def remove_leading_trailing_nonalpha(s: bytes) -> bytes:

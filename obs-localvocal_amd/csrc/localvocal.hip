@@ -2,6 +2,9 @@
 // control flow below is this project's own arrangement of the same contract.
 #include "localvocal.hpp"
 
+#include <fstream>
+#include <iterator>
+
 #include "../../include/localvocal_hotpath.h"
 #include "../../include/mi355_whisper.h"
 #include "common.hpp"
@@ -447,6 +450,39 @@ int lv_filter_register_model(lv_filter *f, const char *name, const char *file) {
     if (!f || !name) return -1;
     return lv_guard([&] {
         f->gf.models_info[name] = file ? file : "";
+        return 0;
+    });
+}
+int lv_filter_load_catalogue(lv_filter *f, const char *json_path, const char *data_models_dir, const char *config_models_dir) {
+    if (!f || !json_path) return -1;
+    return lv_guard([&] {
+        std::ifstream in(json_path, std::ios::binary);
+        if (!in) throw std::runtime_error(std::string("cannot open ") + json_path);
+        const std::string text((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+        f->gf.catalogue = load_models_info(text);
+        int n = 0;
+        for (const auto &kv : f->gf.catalogue) {
+            if (kv.second.type != MODEL_TYPE_TRANSCRIPTION) continue;
+            f->gf.models_info[kv.first] = find_model_bin_file(kv.second, data_models_dir ? data_models_dir : "",
+                                                              config_models_dir ? config_models_dir : "");
+            ++n;
+        }
+        return n;
+    });
+}
+int lv_filter_verify_model(lv_filter *f, const char *friendly_name) {
+    if (!f || !friendly_name) return -1;
+    return lv_guard([&] {
+        const auto it = f->gf.catalogue.find(friendly_name);
+        const auto fit = f->gf.models_info.find(friendly_name);
+        if (it == f->gf.catalogue.end() || fit == f->gf.models_info.end() || fit->second.empty()) return 2;
+        return verify_model_file(it->second, fit->second);
+    });
+}
+int lv_model_file_sha256(const char *path, char *out_hex, size_t n) {
+    if (!path || !out_hex || n < 65) return -1;
+    return lv_guard([&] {
+        snprintf(out_hex, n, "%s", sha256_file(path).c_str());
         return 0;
     });
 }

@@ -29,6 +29,7 @@
 #pragma once
 
 #include "../../include/whisper.h"
+#include "catalogue.hpp"
 
 #include <atomic>
 #include <condition_variable>
@@ -250,6 +251,7 @@ struct transcription_filter_data {
     // the downloader behind it is out of scope)
     lv_settings *context = nullptr;
     std::map<std::string, std::string> models_info;
+    std::map<std::string, ModelInfo> catalogue;  // what lv_filter_load_catalogue parsed (digests for lv_filter_verify_model)
 
     std::thread whisper_thread;
     std::mutex whisper_buf_mutex;
