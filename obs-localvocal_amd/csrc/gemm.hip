@@ -686,13 +686,62 @@ __global__ __launch_bounds__(512) void gemm_bf16_256_kernel(GemmArgs a) {
             }
             par ^= 1;
         }
-        // epilogue of this tile while step 0 of the next one is in flight (it touches no LDS)
-        int m0e = m0, n0e = n0;
-        asm volatile("" : "+s"(m0e), "+s"(n0e));  // opaque: nothing of the epilogue (bias loads, addresses) is computed before the k-loop
+        // Epilogue of this tile while step 0 of the next one is in flight.  Written straight from the MFMA layout the tile went
+        // out as 32-byte pieces of 16 different rows per store instruction, all 256 CUs at the same moment: 16-17 us per tile
+        // in which the matrix cores idle.  Here every 16-row slice of the wave's 128 x 64 block is turned through a
+        // wave-private corner of the k-step buffer that was read last (free behind the barrier below; LDS operations of
+        // one wave execute in order, so no further barrier), and leaves as whole lines: 16 lanes cover one row's 64 columns
+        // (256 bytes of fp32 / 128 of bf16), the residual is read the same way, the lane's four bias values once.
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave has read the last k-step
+        {
+            constexpr int SROW = 64 + 4;  // floats per staged row (padding: conflict-free 16-byte column accesses)
+            float *stg = reinterpret_cast<float *>(lds + (par ^ 1) * STAGE + wave * (16 * SROW * 4 + 256));
+            const int erow = lane >> 4, ecol = 4 * (lane & 15);  // read side: 4 rows x 64 columns per instruction
+            const int nb = n0 + wc * 64 + ecol;
+            const float4 b4 = *reinterpret_cast<const float4 *>(a.bias ? a.bias + nb : a.epi_zero);
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            f32x4(&part)[4][4] = *reinterpret_cast<f32x4(*)[4][4]>(&acc[hh * 4]);
-            gemm_bf16_epilogue<TOUT, 128, false, 4>(a, part, C, a.bias, a.R, m0e + wr * 128 + hh * 64, n0e + wc * 64, 0, 0, lane);
+            for (int i8 = 0; i8 < 8; ++i8) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 v = acc[i8][j];
+                    v *= a.alpha;
+                    *reinterpret_cast<f32x4 *>(stg + (lane & 15) * SROW + 16 * j + 4 * (lane >> 4)) = v;
+                }
+                const int mrow0 = m0 + wr * 128 + i8 * 16;
+                float4 rv[4];
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int m = min(mrow0 + erow + 4 * it, M - 1);
+                    rv[it] = a.R ? *reinterpret_cast<const float4 *>(a.R + (long)m * a.ldr + nb) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                }
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int mr = mrow0 + erow + 4 * it;
+                    const f32x4 t = *reinterpret_cast<const f32x4 *>(stg + (erow + 4 * it) * SROW + ecol);
+                    float x[4] = {t[0], t[1], t[2], t[3]};
+                    const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, rr[4] = {rv[it].x, rv[it].y, rv[it].z, rv[it].w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (a.bias) x[r] += bb[r];
+                        if (a.act == ACT_GELU) x[r] = gelu_fast(x[r]);
+                        if (a.R) x[r] += rr[r];
+                    }
+                    TOUT *dst = C + (long)min(mr, M - 1) * a.ldc + nb;
+                    if (mr < M) {
+                        if constexpr (sizeof(TOUT) == 4) {
+                            *reinterpret_cast<float4 *>(dst) = make_float4(x[0], x[1], x[2], x[3]);  // the residual stream: read again at once
+                        } else {
+                            __hip_bfloat16 h0 = __float2bfloat16(x[0]), h1 = __float2bfloat16(x[1]), h2 = __float2bfloat16(x[2]),
+                                           h3 = __float2bfloat16(x[3]);
+                            using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+                            u32x2 pk;
+                            pk.x = (unsigned)*reinterpret_cast<bf16_t *>(&h0) | ((unsigned)*reinterpret_cast<bf16_t *>(&h1) << 16);
+                            pk.y = (unsigned)*reinterpret_cast<bf16_t *>(&h2) | ((unsigned)*reinterpret_cast<bf16_t *>(&h3) << 16);
+                            __builtin_nontemporal_store(pk, reinterpret_cast<u32x2 *>(dst));  // 60-120 MB read once by the next kernel
+                        }
+                    }
+                }
+            }
         }
         m0 = m1;
         n0 = n1;
@@ -745,7 +794,7 @@ void launch_gemm(const GemmArgs &args, DType in, DType out, hipStream_t st) {
     // Q|K and fc1 from M = 6000 on
     const long tiles256 = (long)(a.N / 256) * ceil_div(a.M, 256);
     const bool big = in == DType::BF16 && !a.trans_c && a.K % 64 == 0 && a.K >= 256 && a.N % 256 == 0 && a.nz0 * a.nz1 == 1 &&
-                     (a.glds == 8 || (a.glds == 0 && tiles256 >= 200));
+                     a.epi_vec && (a.glds == 8 || (a.glds == 0 && tiles256 >= 200));
     const int bm = big ? 256 : bm64 ? 64 : 128, bn = big ? 256 : BN;
     dim3 grid(ceil_div(a.N, bn), ceil_div(a.M, bm), a.nz0 * a.nz1);
     MW_CHECK(grid.y <= 65535, "gemm: M too large for grid.y");
