@@ -114,7 +114,7 @@ struct Hub {
     // encoder passes of the same contexts, batched the same way on a stream of their own: the windows of up to
     // ENC_MAX_WINDOWS streams run as ONE pass with M = windows x n_ctx rows in every projection (more tiles per launch,
     // one pass over the encoder weights); each window's cross K / V goes to its own context
-    static constexpr int ENC_MAX_WINDOWS = 8;
+    static constexpr int ENC_MAX_WINDOWS = 16;  // measured on 64 turbo streams: 8 -> 6 225, 16 -> 6 460, 32 -> 6 260 audio-s/s
     // ONE encoder lane (stream + workspace).  Two were measured: encoder passes alone 3.88 -> 3.75 ms per window (the second pass
     // fills the LayerNorm / V-projection / tail gaps of the first), but 64 streams with their decode steps beside them
     // 5 985 -> 5 650 audio-s/s: two chip-filling GEMMs at a time leave the latency-bound step kernels even fewer CUs.
