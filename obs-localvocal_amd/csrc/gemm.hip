@@ -789,7 +789,7 @@ void launch_gemm(const GemmArgs &args, DType in, DType out, hipStream_t st) {
     const bool bm64 = in == DType::BF16 && tiles128 < 300 && a.M > 64;
     // many-tile grids (the encoder pass over the windows of several streams, M = windows x 1500): the single-stage LDS-direct
     // kernel, four workgroups per CU
-    const bool many = in == DType::BF16 && !a.trans_c && a.K % 64 == 0 && a.K >= 256 && tiles128 >= 900;
+    const bool many = in == DType::BF16 && a.K % 64 == 0 && a.K >= 256 && tiles128 >= 900;  // (also the transposed V projection)
     // 256 x 256 persistent tiles once they fill the chip (>= 200 of them for 256 CUs): fc2 / attention output at M = 12000,
     // Q|K and fc1 from M = 6000 on
     const long tiles256 = (long)(a.N / 256) * ceil_div(a.M, 256);
@@ -838,9 +838,11 @@ void launch_gemm(const GemmArgs &args, DType in, DType out, hipStream_t st) {
         if (out == DType::F32) hipLaunchKernelGGL((gemm_bf16_256_kernel<float>), pgrid, dim3(512), 0, st, a);
         else hipLaunchKernelGGL((gemm_bf16_256_kernel<bf16_t>), pgrid, dim3(512), 0, st, a);
     } else if (many && out == DType::F32) {
-        hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, 128, false, 1>), grid, dim3(256), 0, st, a);
+        if (a.trans_c) hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, 128, true, 1>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, 128, false, 1>), grid, dim3(256), 0, st, a);
     } else if (many) {
-        hipLaunchKernelGGL((gemm_bf16_glds_kernel<bf16_t, 128, false, 1>), grid, dim3(256), 0, st, a);
+        if (a.trans_c) hipLaunchKernelGGL((gemm_bf16_glds_kernel<bf16_t, 128, true, 1>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gemm_bf16_glds_kernel<bf16_t, 128, false, 1>), grid, dim3(256), 0, st, a);
     } else if (in == DType::F32 && out == DType::F32)
         hipLaunchKernelGGL((gemm_nt_kernel<float, float, 128>), grid, dim3(256), 0, st, a);
     else if (glds && out == DType::F32 && bm64)
