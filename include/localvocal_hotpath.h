@@ -157,6 +157,24 @@ int lv_filter_model_state(lv_filter *f, char *model_path, size_t n_path, char *f
 /* VadIterator::process + get_speech_timestamps (silero-vad-onnx.cpp:262-309) on a standalone iterator
    with the filter's gate: writes up to cap (start,end) sample pairs, returns the count. */
 int lv_vad_speech_timestamps(lv_filter *f, const float *pcm, size_t n, int reset_state, int *pairs, int cap);
+/* The Silero VAD network behind VadIterator::predict_one (silero-vad-onnx.cpp:111-140: one Ort::Session::Run per 32 ms
+   window on models/silero-vad/silero_vad.onnx) as HIP kernels that score every window of a process() call in one pass.
+   lv_filter_set_silero_model: what obs_module_file("models/silero-vad/silero_vad.onnx") resolves to
+   (whisper-model-utils.cpp:49-56); 0 = the filter's VadIterator now runs the network on the filter's GPU, 1 = no such
+   file (the energy gate stands in, logged), < 0 = the file is not a Silero v5 graph (mw_last_error()). */
+int lv_filter_set_silero_model(lv_filter *f, const char *path);
+int lv_filter_vad_is_silero(lv_filter *f);
+/* speech probabilities of the windows of the last VadIterator::process call; returns their count, writes up to cap */
+int lv_filter_vad_probabilities(lv_filter *f, float *out, int cap);
+/* the network alone (VadIterator::predict_one over consecutive 512-sample windows, state carried between calls unless
+   reset: silero-vad-onnx.cpp:95-109,262-284); wav and probs are host buffers */
+void *lv_silero_create(const char *onnx_path, int device);
+int lv_silero_process(void *h, const float *wav, int n_windows, int reset, float *probs);
+int lv_silero_state(void *h, float *hc256); /* the model's `state` tensor: h[128], c[128] */
+void lv_silero_destroy(void *h);
+/* host only: position-weighted sums of the 15 tensors the ONNX reader takes from the file, in the order basis,
+   encoder.{0..3}.{weight,bias}, rnn.weight_ih, weight_hh, bias_ih, bias_hh, decoder.2.weight, bias; returns 15 */
+int lv_silero_inspect(const char *onnx_path, double *sums, int cap);
 /* remove_leading_trailing_nonalpha (transcription-utils.cpp:91-129) */
 void lv_remove_leading_trailing_nonalpha(const char *in, char *out, size_t n);
 /* stream_resampler: feeds one packet, returns the number of 16 kHz samples written (<= cap) */

@@ -118,6 +118,8 @@ EXPORTED_SYMBOLS = [
     "lv_filter_start", "lv_filter_stop", "lv_filter_update_model", "lv_filter_register_model", "lv_filter_model_state",
     "lv_filter_load_catalogue", "lv_filter_verify_model", "lv_model_file_sha256",
     "lv_vad_speech_timestamps", "lv_remove_leading_trailing_nonalpha",
+    "lv_filter_set_silero_model", "lv_filter_vad_is_silero", "lv_filter_vad_probabilities",
+    "lv_silero_create", "lv_silero_process", "lv_silero_state", "lv_silero_destroy", "lv_silero_inspect",
     "lv_resample",
 ]
 
@@ -272,6 +274,16 @@ def lib():
                                         C.POINTER(C.c_int)]
     L.lv_vad_speech_timestamps.argtypes = [P, FP, C.c_size_t, C.c_int, C.POINTER(C.c_int), C.c_int]
     L.lv_remove_leading_trailing_nonalpha.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+    L.lv_filter_set_silero_model.argtypes = [P, C.c_char_p]
+    L.lv_filter_vad_is_silero.argtypes = [P]
+    L.lv_filter_vad_probabilities.argtypes = [P, FP, C.c_int]
+    L.lv_silero_create.argtypes = [C.c_char_p, C.c_int]
+    L.lv_silero_create.restype = C.c_void_p
+    L.lv_silero_process.argtypes = [C.c_void_p, FP, C.c_int, C.c_int, FP]
+    L.lv_silero_state.argtypes = [C.c_void_p, FP]
+    L.lv_silero_destroy.argtypes = [C.c_void_p]
+    L.lv_silero_destroy.restype = None
+    L.lv_silero_inspect.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.c_int]
     L.lv_resample.argtypes = [P, FPP, C.c_uint32, FP, C.c_int]
     _lib = L
     return L
@@ -283,6 +295,51 @@ def _fp(a: np.ndarray):
 
 def last_error() -> str:
     return (lib().mw_last_error() or b"").decode(errors="replace")
+
+
+class SileroVad:
+    """The Silero VAD network on one GPU (VadIterator::predict_one over consecutive 512-sample windows)."""
+    WINDOW = 512
+
+    def __init__(self, onnx_path: str, device: int = 0):
+        self.L = lib()
+        self.h = self.L.lv_silero_create(onnx_path.encode(), device)
+        if not self.h:
+            raise RuntimeError("lv_silero_create: " + last_error())
+
+    def process(self, wav, reset: bool = True) -> np.ndarray:
+        wav = np.ascontiguousarray(wav, dtype=np.float32)
+        n = len(wav) // self.WINDOW
+        probs = np.zeros(max(n, 1), dtype=np.float32)
+        if self.L.lv_silero_process(self.h, _fp(wav), n, int(reset), _fp(probs)) != 0:
+            raise RuntimeError("lv_silero_process: " + last_error())
+        return probs[:n].copy()
+
+    def state(self) -> np.ndarray:
+        out = np.zeros(256, dtype=np.float32)
+        if self.L.lv_silero_state(self.h, _fp(out)) != 0:
+            raise RuntimeError("lv_silero_state: " + last_error())
+        return out
+
+    def close(self):
+        if self.h:
+            self.L.lv_silero_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def silero_inspect(onnx_path: str):
+    """Host only: position-weighted sums of the 15 tensors the library's ONNX reader takes from the file."""
+    sums = (C.c_double * 15)()
+    n = lib().lv_silero_inspect(onnx_path.encode(), sums, 15)
+    if n != 15:
+        raise RuntimeError("lv_silero_inspect: " + last_error())
+    return [sums[i] for i in range(15)]
 
 
 class Engine:
@@ -550,6 +607,19 @@ class Filter:
         if n < 0:
             raise RuntimeError("lv_vad_speech_timestamps failed")
         return [(pairs[2 * i], pairs[2 * i + 1]) for i in range(min(n, cap))]
+
+    def set_silero_model(self, path) -> int:
+        """0: the filter's VAD is the Silero network on the GPU; 1: no such file (energy gate); raises on a malformed file."""
+        rc = self.L.lv_filter_set_silero_model(self.f, (path or "").encode())
+        if rc < 0:
+            raise RuntimeError("lv_filter_set_silero_model: " + last_error())
+        return rc
+
+    def vad_probabilities(self):
+        n = self.L.lv_filter_vad_probabilities(self.f, None, 0)
+        out = np.zeros(max(n, 1), dtype=np.float32)
+        self.L.lv_filter_vad_probabilities(self.f, _fp(out), n)
+        return out[:max(n, 0)].copy()
 
     def resample(self, data):
         chans, arr = self._planar(data)

@@ -1,6 +1,7 @@
 // localvocal.hip — see localvocal.hpp.  Written against the reference's observable behaviour; the
 // control flow below is this project's own arrangement of the same contract.
 #include "localvocal.hpp"
+#include "silero_vad.hpp"
 
 #include <fstream>
 #include <iterator>
@@ -227,8 +228,7 @@ lv_detection flatten(const DetectionResultWithText &r) {
 }
 
 void make_vad(lv_filter *f) {
-    f->gf.vad.reset(new VadIterator(VadIterator::energy_gate(f->gate_db, f->slope_db), WHISPER_SAMPLE_RATE, 32, f->vad_threshold,
-                                    100, 100, 100));
+    f->gf.vad.reset(build_vad(f->gf.silero_vad_model_file.c_str(), f->gf.gpu_device, f->gate_db, f->slope_db, f->vad_threshold));
 }
 
 // every entry below returns an error code instead of letting an exception cross the C boundary
@@ -431,7 +431,8 @@ int lv_filter_start(lv_filter *f, const char *model_path) {
     if (!f || !model_path) return -1;
     return lv_guard([&] {
         if (f->gf.whisper_context != nullptr) return -2;
-        start_whisper_thread_with_path(&f->gf, model_path, "silero-vad/silero_vad.onnx");
+        start_whisper_thread_with_path(&f->gf, model_path,
+                                       f->gf.silero_vad_model_file.empty() ? "silero-vad/silero_vad.onnx" : f->gf.silero_vad_model_file.c_str());
         if (f->gf.whisper_context == nullptr) return -3;
         f->gf.whisper_model_path = model_path;
         make_vad(f);  // keep the gate configured through lv_filter_set_vad_gate
@@ -522,6 +523,61 @@ int lv_vad_speech_timestamps(lv_filter *f, const float *pcm, size_t n, int reset
         return (int)st.size();
     });
 }
+int lv_filter_set_silero_model(lv_filter *f, const char *path) {
+    if (!f) return -1;
+    return lv_guard([&] {
+        f->gf.silero_vad_model_file = path ? path : "";
+        make_vad(f);  // throws (-> -100, mw_last_error) when the file is there but is not a Silero v5 graph
+        return f->gf.vad->has_batch_source() ? 0 : 1;
+    });
+}
+int lv_filter_vad_is_silero(lv_filter *f) { return f && f->gf.vad && f->gf.vad->has_batch_source() ? 1 : 0; }
+int lv_filter_vad_probabilities(lv_filter *f, float *out, int cap) {
+    if (!f || !f->gf.vad || (!out && cap > 0)) return -1;
+    const std::vector<float> &p = f->gf.vad->last_probabilities();
+    for (int i = 0; i < (int)p.size() && i < cap; ++i) out[i] = p[(size_t)i];
+    return (int)p.size();
+}
+int lv_silero_inspect(const char *path, double *sums, int cap) {
+    if (!path || (!sums && cap > 0)) return -1;
+    return lv_guard([&] {
+        const mw::SileroWeights w = mw::load_silero_onnx(path);
+        const std::vector<float> out_b{w.out_b};
+        const std::vector<float> *t[15] = {&w.basis, &w.c_w[0], &w.c_b[0], &w.c_w[1], &w.c_b[1], &w.c_w[2], &w.c_b[2], &w.c_w[3],
+                                           &w.c_b[3], &w.w_ih, &w.w_hh, &w.b_ih, &w.b_hh, &w.out_w, &out_b};
+        for (int k = 0; k < 15 && k < cap; ++k) {
+            double s = 0.0;
+            for (size_t i = 0; i < t[k]->size(); ++i) s += (double)((i % 7) + 1) * (double)(*t[k])[i];
+            sums[k] = s;
+        }
+        return 15;
+    });
+}
+void *lv_silero_create(const char *path, int device) {
+    if (!path) return nullptr;
+    mw::SileroVad *v = nullptr;
+    lv_guard([&] {
+        v = new mw::SileroVad(mw::load_silero_onnx(path), device);
+        return 0;
+    });
+    return v;
+}
+int lv_silero_process(void *h, const float *wav, int n_windows, int reset, float *probs) {
+    if (!h || n_windows < 0 || (n_windows > 0 && (!wav || !probs))) return -1;
+    return lv_guard([&] {
+        static_cast<mw::SileroVad *>(h)->process(wav, n_windows, reset != 0, probs);
+        return 0;
+    });
+}
+int lv_silero_state(void *h, float *hc256) {
+    if (!h || !hc256) return -1;
+    return lv_guard([&] {
+        static_cast<mw::SileroVad *>(h)->get_state(hc256);
+        return 0;
+    });
+}
+void lv_silero_destroy(void *h) { delete static_cast<mw::SileroVad *>(h); }
+
 void lv_remove_leading_trailing_nonalpha(const char *in, char *out, size_t n) {
     if (!in || !out || n == 0) return;
     try {

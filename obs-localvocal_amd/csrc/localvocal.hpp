@@ -129,6 +129,9 @@ class VadIterator {
 public:
     // p(window) in [0,1]; `reset` is true on the first window after the recurrent state was cleared
     using prob_fn = std::function<float(const float *window, size_t n, bool reset)>;
+    // all windows of one process() call at once (the Silero network on the GPU scores them in one pass): probs[j] for the
+    // n_windows consecutive windows of `wav`; `reset` as above.  When set, it replaces prob_fn.
+    using batch_fn = std::function<void(const float *wav, int n_windows, bool reset, float *probs)>;
 
     VadIterator(prob_fn fn, int Sample_rate = 16000, int windows_frame_size = 32, float Threshold = 0.5f,
                 int min_silence_duration_ms = 0, int speech_pad_ms = 32, int min_speech_duration_ms = 32,
@@ -139,6 +142,9 @@ public:
     void drop_chunks(const std::vector<float> &input_wav, std::vector<float> &output_wav) const;
     const std::vector<timestamp_t> get_speech_timestamps() const { return speeches; }
     void set_threshold(float threshold_) { threshold = threshold_; }
+    void set_batch_source(batch_fn fn) { batch = std::move(fn); }
+    bool has_batch_source() const { return (bool)batch; }
+    const std::vector<float> &last_probabilities() const { return probs; }  // of the last process() call (tests)
     int64_t get_window_size_samples() const { return window_size_samples; }
 
     // default probability source: short-time energy gate (logistic in dB around `gate_db`)
@@ -146,9 +152,11 @@ public:
 
 private:
     void reset_states(bool reset_state);
-    void predict(const float *window);
+    void predict(float speech_prob);
 
     prob_fn prob;
+    batch_fn batch;
+    std::vector<float> probs;
     bool state_was_reset = true;
     int64_t window_size_samples;
     int sample_rate;
@@ -261,6 +269,9 @@ struct transcription_filter_data {
 
     // engine placement (the reference only logs cparams.gpu_device, whisper-processing.cpp:62)
     int gpu_device = 0;
+    // what obs_module_file("models/silero-vad/silero_vad.onnx") resolves to on this host (whisper-model-utils.cpp:49-56);
+    // empty or not a file: the energy gate stands in (logged)
+    std::string silero_vad_model_file;
     int precision = -1;  // -1: library default / MI355_WHISPER_PRECISION
     // storage behind the borrowed const char* members of whisper_params
     std::string language_storage, suppress_regex_storage, initial_prompt_storage;
@@ -292,6 +303,9 @@ vad_state vad_disabled_segmentation(transcription_filter_data *gf, vad_state las
 vad_state vad_based_segmentation(transcription_filter_data *gf, vad_state last_vad_state);
 vad_state hybrid_vad_segmentation(transcription_filter_data *gf, vad_state last_vad_state);
 void initialize_vad(transcription_filter_data *gf, const char *silero_vad_model_file);
+// A VadIterator with the reference's parameters (16 kHz, 32 ms windows, 100 / 100 / 100 ms): the Silero network on `device`
+// when `silero_file` names a readable file (throws if that file is not a Silero v5 graph), else the energy gate.
+VadIterator *build_vad(const char *silero_file, int device, float gate_db, float slope_db, float threshold);
 
 void apply_whisper_params_defaults_on_settings(lv_settings *s);
 void apply_whisper_params_from_settings(whisper_full_params &params, lv_settings *settings);

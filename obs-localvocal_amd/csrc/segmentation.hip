@@ -3,6 +3,7 @@
 // libmi355_whisper.so so the whole LocalVocal worker (audio tap -> segmentation -> whisper_full ->
 // result callbacks) can run against the HIP engine without libobs.
 #include "localvocal.hpp"
+#include "silero_vad.hpp"
 
 #include "common.hpp"
 
@@ -194,9 +195,7 @@ void VadIterator::reset_states(bool reset_state) {
 
 // One window of the speech-timestamp automaton: start on p >= threshold, tentative end below
 // threshold-0.15, confirmed end after min_silence, forced split after max_speech.
-void VadIterator::predict(const float *window) {
-    const float p = prob(window, (size_t)window_size_samples, state_was_reset);
-    state_was_reset = false;
+void VadIterator::predict(float p) {
     const unsigned int W = (unsigned int)window_size_samples;
     current_sample += W;
 
@@ -246,8 +245,18 @@ void VadIterator::predict(const float *window) {
 void VadIterator::process(const std::vector<float> &input_wav, bool reset_state) {
     reset_states(reset_state);
     audio_length_samples = (int)input_wav.size();
-    for (int j = 0; j + (int)window_size_samples <= audio_length_samples; j += (int)window_size_samples)
-        predict(input_wav.data() + j);
+    const int n_windows = audio_length_samples / (int)window_size_samples;
+    probs.assign((size_t)n_windows, 0.0f);
+    if (batch) {  // every window of the call in one pass over the device network
+        batch(input_wav.data(), n_windows, state_was_reset, probs.data());
+        if (n_windows > 0) state_was_reset = false;
+    } else {
+        for (int j = 0; j < n_windows; ++j) {
+            probs[(size_t)j] = prob(input_wav.data() + (size_t)j * window_size_samples, (size_t)window_size_samples, state_was_reset);
+            state_was_reset = false;
+        }
+    }
+    for (int j = 0; j < n_windows; ++j) predict(probs[(size_t)j]);
     if (current_speech.start >= 0) {  // speech still open at the end of the buffer
         current_speech.end = audio_length_samples;
         speeches.push_back(current_speech);
@@ -273,11 +282,30 @@ void VadIterator::drop_chunks(const std::vector<float> &in, std::vector<float> &
     out.insert(out.end(), in.begin() + cur, in.end());
 }
 
+VadIterator *build_vad(const char *silero_file, int device, float gate_db, float slope_db, float threshold) {
+    std::unique_ptr<VadIterator> vad(new VadIterator(VadIterator::energy_gate(gate_db, slope_db), WHISPER_SAMPLE_RATE, 32, threshold, 100, 100, 100));
+    bool readable = false;
+    if (silero_file && silero_file[0]) {
+        if (FILE *fp = fopen(silero_file, "rb")) {
+            readable = true;
+            fclose(fp);
+        }
+    }
+    if (readable) {
+        // the reference's Ort::Session on this file (silero-vad-onnx.cpp:47-93), as kernels on the GPU
+        mw::log_msg(kLogDebug, "Create silero VAD: %s\n", silero_file);
+        auto net = std::make_shared<mw::SileroVad>(mw::load_silero_onnx(silero_file), device);
+        MW_CHECK(vad->get_window_size_samples() == mw::SileroVad::WINDOW, "silero: 32 ms windows at 16 kHz");
+        vad->set_batch_source([net](const float *wav, int n_windows, bool reset, float *probs) { net->process(wav, n_windows, reset, probs); });
+    } else {
+        mw::log_msg(kLogWarn, "Silero VAD model file not found (%s): the energy gate stands in\n", silero_file ? silero_file : "");
+    }
+    return vad.release();
+}
+
 void initialize_vad(transcription_filter_data *gf, const char *silero_vad_model_file) {
-    // The reference loads silero_vad.onnx through ONNX Runtime here; neither exists in this image.
-    // Same iterator parameters (16 kHz, 32 ms windows, 0.5, 100/100/100 ms), energy-gate probability.
-    mw::log_msg(kLogDebug, "Create VAD (energy gate standing in for %s)\n", silero_vad_model_file ? silero_vad_model_file : "silero");
-    gf->vad.reset(new VadIterator(VadIterator::energy_gate(), WHISPER_SAMPLE_RATE, 32, 0.5f, 100, 100, 100));
+    // vad-processing.cpp:456-478: VadIterator(model, 16 kHz, 32 ms windows, 0.5, 100 / 100 / 100 ms)
+    gf->vad.reset(build_vad(silero_vad_model_file, gf->gpu_device, -40.0f, 3.0f, 0.5f));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -757,7 +785,7 @@ void update_whisper_model(transcription_filter_data *gf) {
         mw::log_msg(kLogWarn, "External model file path is empty\n");
         return;
     }
-    const char *silero = "models/silero-vad/silero_vad.onnx";
+    const char *silero = gf->silero_vad_model_file.empty() ? "models/silero-vad/silero_vad.onnx" : gf->silero_vad_model_file.c_str();
     if (gf->whisper_model_path.empty() || gf->whisper_model_path != new_model_path || is_external_model) {
         if (gf->whisper_model_path != new_model_path) {
             mw::log_msg(kLogDebug, "model path changed from %s to %s\n", gf->whisper_model_path.c_str(), new_model_path.c_str());

@@ -40,7 +40,11 @@ class VadIteratorOracle:
     """silero-vad-onnx.cpp:326-353 (constructor arithmetic) + :95-109 + :142-284."""
 
     def __init__(self, threshold=0.5, sample_rate=16000, window_ms=32, min_silence_ms=100, speech_pad_ms=100,
-                 min_speech_ms=100, max_speech_s=float("inf"), gate_db=-40.0, slope_db=3.0):
+                 min_speech_ms=100, max_speech_s=float("inf"), gate_db=-40.0, slope_db=3.0, prob_source=None):
+        # prob_source: an object with process(wav, reset) -> probabilities of wav's consecutive windows (the Silero
+        # restatement, oracle/silero_vad_oracle.py: recurrent state carried between calls unless reset); None: energy gate
+        self.prob_source = prob_source
+        self._was_reset = True
         self.threshold = float(np.float32(threshold))
         sr_per_ms = sample_rate // 1000
         self.W = window_ms * sr_per_ms
@@ -61,14 +65,14 @@ class VadIteratorOracle:
     def _reset(self, reset_state: bool):
         if reset_state:
             self.triggered = False
+            self._was_reset = True
         self.temp_end = 0
         self.current_sample = 0
         self.prev_end = self.next_start = 0
         self.speeches = []
         self.cur_start = -1
 
-    def _predict(self, w: np.ndarray):
-        p = energy_gate_prob(w, *self.gate)
+    def _predict(self, p: float):
         self.current_sample += self.W
         if p >= self.threshold:                                     # :150-169
             if self.temp_end != 0:
@@ -116,10 +120,16 @@ class VadIteratorOracle:
     def process(self, wav: np.ndarray, reset_state: bool = True):   # :262-284
         self._reset(reset_state)
         n = len(wav)
-        j = 0
-        while j + self.W <= n:
-            self._predict(wav[j:j + self.W])
-            j += self.W
+        nw = n // self.W
+        if self.prob_source is not None:
+            probs = self.prob_source.process(np.asarray(wav[:nw * self.W], np.float32), self._was_reset)
+            if nw > 0:
+                self._was_reset = False
+        else:
+            probs = [energy_gate_prob(wav[j * self.W:(j + 1) * self.W], *self.gate) for j in range(nw)]
+        self.probs = np.asarray(probs, np.float32)
+        for j in range(nw):
+            self._predict(float(probs[j]))
         if self.cur_start >= 0:
             self.speeches.append((self.cur_start, n))
             self.cur_start = -1

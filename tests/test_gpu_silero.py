@@ -1,0 +1,121 @@
+"""GPU: the Silero VAD network as HIP kernels (csrc/silero_vad.hip) against its CPU restatement
+(oracle/silero_vad_oracle.py) — SURVEY.md §8 f2; the reference side is VadIterator::predict_one / process,
+/root/reference/src/whisper-utils/silero-vad-onnx.cpp:111-140, 262-284, driven from vad_based_segmentation
+(/root/reference/src/whisper-utils/vad-processing.cpp:202-367).
+
+Weights: synthetic, of the graph's shapes, in an .onnx file of the real file's nesting (the GPU box has no
+/root/reference; tests/test_silero_cpu.py checks both readers on the reference's own file where it exists).
+Tolerance: fp32 both sides, different summation orders (the restatement accumulates in float64): |dp| < 1e-4 on the
+probabilities, 1e-3 on the recurrent state after 250 windows.  PARITY UNPINNED (no ONNX Runtime here, no expected
+outputs in the reference).
+"""
+import numpy as np
+import pytest
+
+from oracle import segmentation_oracle as sg
+from oracle import silero_vad_oracle as so
+from test_segmentation_cpu import drive, speechlike
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(300)]
+W = 512
+
+
+@pytest.fixture(scope="module")
+def model(tmp_path_factory):
+    w = so.synth_weights(11)
+    path = str(tmp_path_factory.mktemp("silero") / "silero_synth.onnx")
+    so.write_onnx(path, w)
+    return path, w
+
+
+def test_probabilities_and_state_match_the_restatement(pkg, model):
+    path, w = model
+    vad = pkg.SileroVad(path)
+    try:
+        x = speechlike(21, 8.0)
+        got = vad.process(x, reset=True)
+        orc = so.SileroOracle(w)
+        want = orc.process(x, reset=True)
+        assert len(got) == len(x) // W == len(want)
+        assert want.min() < 0.2 and want.max() > 0.9            # the signal drives the detector both ways
+        err = float(np.abs(got - want).max())
+        print(f"silero probabilities: max |gpu - restatement| = {err:.2e} over {len(got)} windows")
+        assert err < 1e-4
+        state = vad.state()
+        assert np.abs(state[:128] - orc.h).max() < 1e-3 and np.abs(state[128:] - orc.c).max() < 1e-3
+    finally:
+        vad.close()
+
+
+def test_state_carries_between_calls_and_reset_clears_it(pkg, model):
+    path, _ = model
+    vad = pkg.SileroVad(path)
+    try:
+        x = speechlike(22, 6.0)
+        whole = vad.process(x, reset=True)
+        cut = 57 * W
+        first = vad.process(x[:cut], reset=True)
+        second = vad.process(x[cut:], reset=False)
+        assert np.array_equal(np.concatenate([first, second]), whole)        # the same arithmetic, window by window
+        assert not np.array_equal(vad.process(x[cut:], reset=True), second)  # ... which the state is part of
+        assert np.array_equal(vad.process(x, reset=True), whole)
+        # ragged tail ignored (VadIterator::process stops at the last whole window), nothing to do for less than a window
+        assert np.array_equal(vad.process(x[:cut + 100], reset=True), first)
+        before = vad.state()
+        assert len(vad.process(x[:100], reset=False)) == 0 and np.array_equal(vad.state(), before)
+        assert len(vad.process(x[:0], reset=True)) == 0 and not vad.state().any()
+        # many windows in one call (10 minutes): the recurrent kernel's loop is bounded by its argument
+        long = np.tile(x, 100)
+        p = vad.process(long, reset=True)
+        assert len(p) == len(long) // W and np.isfinite(p).all() and np.array_equal(p[:len(whole)], whole)
+    finally:
+        vad.close()
+
+
+def test_vad_iterator_on_the_network_matches_the_restatement(pkg, model):
+    path, w = model
+    f = pkg.Filter()
+    try:
+        assert f.set_silero_model(path) == 0 and f.L.lv_filter_vad_is_silero(f.f) == 1
+        for seed in (70, 72, 73, 76, 79):   # (signals on which the restatement's probabilities keep the margin asserted below)
+            x = speechlike(seed, 12.0, burst=(0.05, 1.5), gap=(0.05, 0.6))
+            orc = sg.VadIteratorOracle(prob_source=so.SileroOracle(w))
+            want = orc.process(x, True)
+            # the comparison is of decisions: it needs every probability clear of both thresholds by more than the tolerance
+            assert min(np.abs(orc.probs - 0.5).min(), np.abs(orc.probs - 0.35).min()) > 1e-3
+            assert f.vad_speech_timestamps(x, True) == want and len(want) >= 2
+            assert np.abs(f.vad_probabilities() - orc.probs).max() < 1e-4
+        # without a reset the network's state carries into the next buffer, on both sides
+        orc = sg.VadIteratorOracle(prob_source=so.SileroOracle(w))
+        a, b = speechlike(90, 4.0), speechlike(91, 4.0)
+        assert f.vad_speech_timestamps(a, True) == orc.process(a, True)
+        assert f.vad_speech_timestamps(b, False) == orc.process(b, False)
+        assert np.abs(f.vad_probabilities() - orc.probs).max() < 1e-4
+    finally:
+        f.close()
+
+
+@pytest.mark.parametrize("mode", [sg.VAD_MODE_ACTIVE, sg.VAD_MODE_HYBRID])
+def test_segmentation_driven_by_the_network_matches_the_restatement(pkg, model, mode):
+    path, w = model
+    got, want, states = drive(pkg, mode, True, 3, seconds=20.0, silero=(path, so.SileroOracle(w)))
+    for a, b in states:
+        assert a == b
+    assert len(got) == len(want) >= 2
+    for (pcm, t0, t1, vs), r in zip(got, want):
+        assert (t0, t1, vs) == (r.t0, r.t1, r.vad_state) and np.array_equal(pcm, r.pcm)
+
+
+def test_a_file_that_is_not_the_graph_is_refused(pkg, model, tmp_path):
+    path, _ = model
+    cut = str(tmp_path / "cut.onnx")
+    blob = open(path, "rb").read()
+    open(cut, "wb").write(blob[:len(blob) // 2])
+    f = pkg.Filter()
+    try:
+        with pytest.raises(RuntimeError):
+            f.set_silero_model(cut)
+    finally:
+        f.close()
+    with pytest.raises(RuntimeError):
+        pkg.SileroVad(cut)

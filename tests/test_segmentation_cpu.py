@@ -27,10 +27,13 @@ def speechlike(seed, seconds, burst=(0.4, 2.5), gap=(0.3, 1.0)):
     return x
 
 
-def drive(pkg, mode, partial, seed, seconds=24.0, segment_duration=3000, packet_ms=(10, 400), steps_every=(1, 6)):
+def drive(pkg, mode, partial, seed, seconds=24.0, segment_duration=3000, packet_ms=(10, 400), steps_every=(1, 6), silero=None):
+    """silero = (onnx path, probability source for the restatement): the filter's VAD runs the Silero network on the GPU."""
     x = speechlike(seed, seconds)
     f = pkg.Filter()
     assert f.f
+    if silero is not None:
+        assert f.set_silero_model(silero[0]) == 0
     got = []
     f.set_callbacks(on_request=lambda pcm, t0, t1, vs: got.append((pcm, t0, t1, vs)))
     f.setup_audio(SR, 1)
@@ -38,7 +41,8 @@ def drive(pkg, mode, partial, seed, seconds=24.0, segment_duration=3000, packet_
     f.L.lv_filter_set_partial(f.f, int(partial), 1100)
     f.L.lv_filter_set_segment_duration(f.f, segment_duration)
     orc = so.SegmenterOracle(vad_mode=mode, partial_transcription=partial, partial_latency=1100,
-                             segment_duration=segment_duration)
+                             segment_duration=segment_duration,
+                             **({} if silero is None else {"vad": so.VadIteratorOracle(prob_source=silero[1])}))
     rng = np.random.RandomState(seed + 1000)
     pos, k, states = 0, 0, []
     base_ns = 1_000_000_000

@@ -1,0 +1,44 @@
+"""Development aid: time the Silero VAD pass (csrc/silero_vad.hip) on buffers of the sizes vad_based_segmentation sends
+(new audio since the last step: 0.1 - 10 s) and print the deviation from the CPU restatement on synthetic weights."""
+import importlib
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import silero_vad_oracle as so  # noqa: E402  (checker only)
+
+pkg = importlib.import_module("obs-localvocal_amd")
+
+
+def main():
+    w = so.synth_weights(11)
+    path = os.path.join(tempfile.mkdtemp(), "silero_synth.onnx")
+    so.write_onnx(path, w)
+    vad = pkg.SileroVad(path)
+    rng = np.random.default_rng(0)
+    x = (0.05 * rng.standard_normal(16000 * 10)).astype(np.float32)
+    x[16000 * 3:16000 * 5] *= 0.01
+    got = vad.process(x)
+    t0 = time.time()
+    want = so.SileroOracle(w).process(x)
+    t_cpu = time.time() - t0
+    print(f"max |gpu - restatement| = {np.abs(got - want).max():.2e} over {len(got)} windows; restatement {t_cpu * 1e3:.0f} ms")
+    for seconds in (0.1, 0.5, 1.0, 3.0, 10.0):
+        n = int(seconds * 16000)
+        for _ in range(3):
+            vad.process(x[:n])
+        t0 = time.time()
+        reps = 20
+        for _ in range(reps):
+            vad.process(x[:n])
+        dt = (time.time() - t0) / reps
+        print(f"{seconds:5.1f} s of audio ({n // 512:3d} windows): {dt * 1e3:.3f} ms per call from host PCM = {seconds / dt:,.0f} x real time")
+    vad.close()
+
+
+if __name__ == "__main__":
+    main()
