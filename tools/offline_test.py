@@ -15,8 +15,9 @@ longer token count) without the Levenshtein package.
 usage: offline_test.py <audio.wav> <config.json> [--outdir DIR]
 config keys honoured: whisper_model_path, whisper_language, whisper_sampling_method, temperature, no_context,
 enable_audio_chunks_callback, vad_mode, partial_transcription, sentence_psum_accept_thresh (extension),
-precision ("bf16"/"fp32", extension).  silero_vad_model_file, ct2_model_folder, source/target_language are accepted
-and ignored (no ONNX Runtime / CTranslate2 in this build; the VAD is the energy gate).
+precision ("bf16"/"fp32", extension), silero_vad_model_file (the Silero network on the GPU when the file exists, else the
+energy gate, as the library logs).  ct2_model_folder, source/target_language are accepted and ignored (no CTranslate2 in
+this build).
 """
 from __future__ import annotations
 
@@ -132,6 +133,8 @@ def run(audio_path, config, outdir=".", pkg=None, realtime=False):
             json.dump(segments, fh, indent=4)
 
     try:
+        if config.get("silero_vad_model_file"):
+            f.set_silero_model(config["silero_vad_model_file"])   # (localvocal-offline-test.cpp passes it to start_whisper_thread_with_path)
         f.setup_audio(sr, len(chans))
         # create_context(): the harness's parameter set
         p = f.L.whisper_full_default_params(int(config.get("whisper_sampling_method", 0)))
