@@ -14,7 +14,7 @@ longer token count) without the Levenshtein package.
 
 usage: offline_test.py <audio.wav> <config.json> [--outdir DIR]
 config keys honoured: whisper_model_path, whisper_language, whisper_sampling_method, temperature, no_context,
-enable_audio_chunks_callback, vad_mode, partial_transcription, sentence_psum_accept_thresh (extension),
+enable_audio_chunks_callback, vad_mode, partial_transcription, sentence_psum_accept_thresh, duration_filter_threshold, temperature_inc (extensions),
 precision ("bf16"/"fp32", extension), silero_vad_model_file (the Silero network on the GPU when the file exists, else the
 energy gate, as the library logs).  ct2_model_folder, source/target_language are accepted and ignored (no CTranslate2 in
 this build).
@@ -109,7 +109,8 @@ def wer(ref_tokens, hyp_tokens):
 
 
 # ---- the harness ----
-def run(audio_path, config, outdir=".", pkg=None, realtime=False):
+def run(audio_path, config, outdir=".", pkg=None, realtime=False, requests_out=None):
+    """requests_out: a list that receives (pcm, t0, t1, vad_state) of every inference request (tests replay them on the oracle)."""
     pkg = pkg or load_package()
     sr, chans = read_wav(audio_path)
     prec = {"bf16": pkg.PRECISION_BF16, "fp32": pkg.PRECISION_FP32}.get(config.get("precision", "bf16"), pkg.PRECISION_BF16)
@@ -158,14 +159,18 @@ def run(audio_path, config, outdir=".", pkg=None, realtime=False):
         q.suppress_blank = True
         q.suppress_non_speech_tokens = True
         q.temperature = float(config.get("temperature", 0.0))
+        if "temperature_inc" in config:   # extension: 0 switches the temperature fallback off
+            q.temperature_inc = float(config["temperature_inc"])
         q.max_initial_ts = 1.0
         q.length_penalty = -1.0
         f.L.lv_filter_set_language(f.f, str(config.get("whisper_language", "en")).encode())
-        f.L.lv_filter_set_thresholds(f.f, float(config.get("sentence_psum_accept_thresh", 0.4)), 2.25)
+        f.L.lv_filter_set_thresholds(f.f, float(config.get("sentence_psum_accept_thresh", 0.4)),
+                                     float(config.get("duration_filter_threshold", 2.25)))
         f.L.lv_filter_set_vad_mode(f.f, int(config.get("vad_mode", pkg.VAD_MODE_ACTIVE)))
         f.L.lv_filter_set_partial(f.f, int(bool(config.get("partial_transcription", False))), 1100)
         f.L.lv_filter_enable_audio_chunks_callback(f.f, int(bool(config.get("enable_audio_chunks_callback", True))))
-        f.set_callbacks(on_text=on_text, on_chunk=on_chunk)
+        f.set_callbacks(on_text=on_text, on_chunk=on_chunk,
+                        on_request=None if requests_out is None else (lambda pcm, t0, t1, vs: requests_out.append((pcm, t0, t1, vs))))
         rc = f.start(config["whisper_model_path"])
         if rc != 0:
             raise RuntimeError("failed to start the whisper thread: %d (%s)" % (rc, pkg.last_error()))
