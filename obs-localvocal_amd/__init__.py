@@ -141,13 +141,9 @@ def build(force: bool = False) -> str:
 _lib = None
 
 
-def lib():
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise RuntimeError("libmi355_whisper.so is not built (run __graft_entry__.build()); there is no fallback path")
-    L = C.CDLL(LIB_PATH)
+def bind_whisper_abi(L):
+    """ctypes signatures of the whisper.h symbols LocalVocal binds (include/whisper.h), on any library that exports them:
+    this one, or a whisper.cpp v1.6.2 build named by WHISPER_CPP_LIB (tests/test_pinning_hooks.py)."""
     P = C.c_void_p
     FP = C.POINTER(C.c_float)
     IP = C.POINTER(C.c_int32)
@@ -184,6 +180,19 @@ def lib():
               "whisper_n_vocab", "whisper_n_text_ctx", "whisper_n_audio_ctx", "whisper_n_len", "whisper_is_multilingual"):
         getattr(L, n).argtypes = [P]
     L.whisper_token_lang.argtypes = [P, C.c_int]
+    return L
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libmi355_whisper.so is not built (run __graft_entry__.build()); there is no fallback path")
+    L = bind_whisper_abi(C.CDLL(LIB_PATH))
+    P = C.c_void_p
+    FP = C.POINTER(C.c_float)
+    IP = C.POINTER(C.c_int32)
     L.mw_init_from_file.restype = P
     L.mw_init_from_file.argtypes = [C.c_char_p, C.c_int, C.c_int]
     L.mw_init_from_buffer.restype = P
