@@ -297,8 +297,10 @@ VadIterator *build_vad(const char *silero_file, int device, float gate_db, float
         auto net = std::make_shared<mw::SileroVad>(mw::load_silero_onnx(silero_file), device);
         MW_CHECK(vad->get_window_size_samples() == mw::SileroVad::WINDOW, "silero: 32 ms windows at 16 kHz");
         vad->set_batch_source([net](const float *wav, int n_windows, bool reset, float *probs) { net->process(wav, n_windows, reset, probs); });
+    } else if (silero_file && silero_file[0]) {
+        mw::log_msg(kLogWarn, "Silero VAD model file not found (%s): the energy gate stands in\n", silero_file);
     } else {
-        mw::log_msg(kLogWarn, "Silero VAD model file not found (%s): the energy gate stands in\n", silero_file ? silero_file : "");
+        mw::log_msg(kLogDebug, "no Silero VAD model file configured: energy gate\n");
     }
     return vad.release();
 }
