@@ -171,6 +171,12 @@ int lv_filter_vad_probabilities(lv_filter *f, float *out, int cap);
 void *lv_silero_create(const char *onnx_path, int device);
 int lv_silero_process(void *h, const float *wav, int n_windows, int reset, float *probs);
 int lv_silero_state(void *h, float *hc256); /* the model's `state` tensor: h[128], c[128] */
+/* the windows of several streams (up to 256 handles created from the same file on the same device, each at most once)
+   in one pass: one front-end launch over all windows, one recurrent launch with a workgroup per stream; per stream the
+   same probabilities and state as lv_silero_process.  No counterpart in the reference (one ORT session call per window
+   and source); for hosts that own many sources. */
+int lv_silero_process_batch(void *const *handles, const float *const *wavs, const int *n_windows, const int *resets,
+                            float *const *probs, int n_streams);
 void lv_silero_destroy(void *h);
 /* host only: position-weighted sums of the 15 tensors the ONNX reader takes from the file, in the order basis,
    encoder.{0..3}.{weight,bias}, rnn.weight_ih, weight_hh, bias_ih, bias_hh, decoder.2.weight, bias; returns 15 */

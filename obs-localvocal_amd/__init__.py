@@ -119,7 +119,7 @@ EXPORTED_SYMBOLS = [
     "lv_filter_load_catalogue", "lv_filter_verify_model", "lv_model_file_sha256",
     "lv_vad_speech_timestamps", "lv_remove_leading_trailing_nonalpha",
     "lv_filter_set_silero_model", "lv_filter_vad_is_silero", "lv_filter_vad_probabilities",
-    "lv_silero_create", "lv_silero_process", "lv_silero_state", "lv_silero_destroy", "lv_silero_inspect",
+    "lv_silero_create", "lv_silero_process", "lv_silero_process_batch", "lv_silero_state", "lv_silero_destroy", "lv_silero_inspect",
     "lv_resample",
 ]
 
@@ -290,6 +290,7 @@ def lib():
     L.lv_silero_create.restype = C.c_void_p
     L.lv_silero_process.argtypes = [C.c_void_p, FP, C.c_int, C.c_int, FP]
     L.lv_silero_state.argtypes = [C.c_void_p, FP]
+    L.lv_silero_process_batch.argtypes = [C.POINTER(C.c_void_p), C.POINTER(FP), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(FP), C.c_int]
     L.lv_silero_destroy.argtypes = [C.c_void_p]
     L.lv_silero_destroy.restype = None
     L.lv_silero_inspect.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.c_int]
@@ -340,6 +341,23 @@ class SileroVad:
             self.close()
         except Exception:
             pass
+
+
+def silero_process_batch(vads, wavs, resets):
+    """The windows of several SileroVad streams in one pass; returns one probability array per stream."""
+    n = len(vads)
+    wavs = [np.ascontiguousarray(w, dtype=np.float32) for w in wavs]
+    nw = [len(w) // SileroVad.WINDOW for w in wavs]
+    outs = [np.zeros(max(k, 1), dtype=np.float32) for k in nw]
+    H = (C.c_void_p * n)(*[v.h for v in vads])
+    FP = C.POINTER(C.c_float)
+    Wp = (FP * n)(*[_fp(w) for w in wavs])
+    Pp = (FP * n)(*[_fp(o) for o in outs])
+    N = (C.c_int * n)(*nw)
+    R = (C.c_int * n)(*[int(bool(r)) for r in resets])
+    if lib().lv_silero_process_batch(H, Wp, N, R, Pp, n) != 0:
+        raise RuntimeError("lv_silero_process_batch: " + last_error())
+    return [o[:k].copy() for o, k in zip(outs, nw)]
 
 
 def silero_inspect(onnx_path: str):

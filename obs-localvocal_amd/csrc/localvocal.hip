@@ -569,6 +569,17 @@ int lv_silero_process(void *h, const float *wav, int n_windows, int reset, float
         return 0;
     });
 }
+int lv_silero_process_batch(void *const *handles, const float *const *wavs, const int *n_windows, const int *resets,
+                            float *const *probs, int n_streams) {
+    if (!handles || !wavs || !n_windows || !resets || !probs || n_streams < 1) return -1;
+    return lv_guard([&] {
+        std::vector<mw::SileroBatchItem> items((size_t)n_streams);
+        for (int i = 0; i < n_streams; ++i)
+            items[(size_t)i] = mw::SileroBatchItem{static_cast<mw::SileroVad *>(handles[i]), wavs[i], n_windows[i], resets[i] != 0, probs[i]};
+        mw::SileroVad::process_batch(items.data(), n_streams);
+        return 0;
+    });
+}
 int lv_silero_state(void *h, float *hc256) {
     if (!h || !hc256) return -1;
     return lv_guard([&] {

@@ -320,12 +320,23 @@ __global__ __launch_bounds__(256) void silero_frontend_kernel(const float *__res
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// the recurrent cell over the windows in order: ONE workgroup, thread j = gate row j (i: 0..127, f, g, o)
+struct StreamDesc {  // one stream of a recurrent launch: its windows inside gx / probs and its state
+    float *state;
+    int win0, n_windows;
+};
+
+// the recurrent cell over a stream's windows in order: ONE workgroup per stream (blockIdx.x; `many` null: the single stream
+// `one`), thread j = gate row j (i: 0..127, f, g, o)
 __global__ __launch_bounds__(512) void silero_lstm_kernel(const float *__restrict__ gx, const float *__restrict__ w_hhT,
-                                                         const float *__restrict__ out_w, float out_b, float *__restrict__ state,
-                                                         float *__restrict__ probs, int n_windows) {
+                                                         const float *__restrict__ out_w, float out_b, StreamDesc one,
+                                                         const StreamDesc *__restrict__ many, float *__restrict__ probs) {
     __shared__ float hs[128], ga[512], red[2];
     const int j = threadIdx.x;
+    const StreamDesc D = many ? many[blockIdx.x] : one;
+    float *__restrict__ state = D.state;
+    const int n_windows = D.n_windows;
+    gx += (size_t)D.win0 * 512;
+    probs += D.win0;
     float wr[128];
 #pragma unroll
     for (int k = 0; k < 128; ++k) wr[k] = w_hhT[k * 512 + j];
@@ -397,7 +408,20 @@ SileroVad::SileroVad(const SileroWeights &w, int device) : device_(device) {
     o_bg_ = put(bg);
     o_outw_ = put(w.out_w);
     out_b_ = w.out_b;
+    weights_id_ = 1469598103934665603ull;
+    for (float v : all) {
+        unsigned u;
+        memcpy(&u, &v, 4);
+        weights_id_ = (weights_id_ ^ u) * 1099511628211ull;
+    }
+    {
+        unsigned u;
+        memcpy(&u, &out_b_, 4);
+        weights_id_ = (weights_id_ ^ u) * 1099511628211ull;
+    }
     MW_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+    MW_HIP(hipMalloc(&d_desc_, MAX_BATCH_STREAMS * sizeof(StreamDesc)));
+    MW_HIP(hipHostMalloc(&h_desc_, MAX_BATCH_STREAMS * sizeof(StreamDesc)));
     MW_HIP(hipMalloc((void **)&d_w_, all.size() * sizeof(float)));
     MW_HIP(hipMemcpy(d_w_, all.data(), all.size() * sizeof(float), hipMemcpyHostToDevice));
     MW_HIP(hipMalloc((void **)&d_state_, 256 * sizeof(float)));
@@ -412,6 +436,8 @@ SileroVad::~SileroVad() {
     (void)hipFree(d_wav_);
     (void)hipFree(d_gx_);
     (void)hipFree(d_probs_);
+    (void)hipFree(d_desc_);
+    if (h_desc_) (void)hipHostFree(h_desc_);
     if (h_pin_) (void)hipHostFree(h_pin_);
     if (st_) (void)hipStreamDestroy(st_);
 }
@@ -455,12 +481,67 @@ void SileroVad::process(const float *wav, int n_windows, bool reset, float *prob
     hipLaunchKernelGGL(silero_frontend_kernel, dim3(n_windows), dim3(256), 0, st_, (const float *)d_wav_, W, d_gx_, n_windows);
     MW_HIP(hipGetLastError());
     hipLaunchKernelGGL(silero_lstm_kernel, dim3(1), dim3(512), 0, st_, (const float *)d_gx_, (const float *)(d_w_ + o_whh_),
-                       (const float *)(d_w_ + o_outw_), out_b_, d_state_, d_probs_, n_windows);
+                       (const float *)(d_w_ + o_outw_), out_b_, StreamDesc{d_state_, 0, n_windows}, (const StreamDesc *)nullptr, d_probs_);
     MW_HIP(hipGetLastError());
     float *h_probs = h_pin_ + (size_t)cap_ * WINDOW;
     MW_HIP(hipMemcpyAsync(h_probs, d_probs_, (size_t)n_windows * sizeof(float), hipMemcpyDeviceToHost, st_));
     MW_HIP(hipStreamSynchronize(st_));
     memcpy(probs, h_probs, (size_t)n_windows * sizeof(float));
+}
+
+void SileroVad::process_batch(const SileroBatchItem *items, int n) {
+    MW_CHECK(items && n >= 1 && n <= MAX_BATCH_STREAMS, "silero: batch of 1..256 streams");
+    SileroVad &L = *items[0].vad;  // the leader: its stream, staging and weights serve the whole batch
+    long total = 0;
+    for (int i = 0; i < n; ++i) {
+        const SileroBatchItem &it = items[i];
+        MW_CHECK(it.vad && it.n_windows >= 0 && (it.n_windows == 0 || (it.wav && it.probs)), "silero: batch item");
+        MW_CHECK(it.vad->device_ == L.device_ && it.vad->weights_id_ == L.weights_id_, "silero: a batch shares one model on one device");
+        for (int k = 0; k < i; ++k) MW_CHECK(items[k].vad != it.vad, "silero: a stream appears once per batch");
+        total += it.n_windows;
+    }
+    MW_CHECK(total <= (1 << 24), "silero: batch too large");
+    MW_HIP(hipSetDevice(L.device_));
+    for (int i = 0; i < n; ++i) {
+        // another stream's own launches (an earlier process() on its own HIP stream) must be done with its state
+        if (items[i].vad != &L) MW_HIP(hipStreamSynchronize(items[i].vad->st_));
+        if (items[i].reset) MW_HIP(hipMemsetAsync(items[i].vad->d_state_, 0, 256 * sizeof(float), L.st_));
+    }
+    if (total == 0) {
+        MW_HIP(hipStreamSynchronize(L.st_));
+        return;
+    }
+    L.reserve((int)total);
+    StreamDesc *hd = static_cast<StreamDesc *>(L.h_desc_);
+    long at = 0;
+    for (int i = 0; i < n; ++i) {
+        hd[i] = StreamDesc{items[i].vad->d_state_, (int)at, items[i].n_windows};
+        if (items[i].n_windows) memcpy(L.h_pin_ + at * WINDOW, items[i].wav, (size_t)items[i].n_windows * WINDOW * sizeof(float));
+        at += items[i].n_windows;
+    }
+    MW_HIP(hipMemcpyAsync(L.d_wav_, L.h_pin_, (size_t)total * WINDOW * sizeof(float), hipMemcpyHostToDevice, L.st_));
+    MW_HIP(hipMemcpyAsync(L.d_desc_, hd, (size_t)n * sizeof(StreamDesc), hipMemcpyHostToDevice, L.st_));
+    FrontW W;
+    W.basisT = L.d_w_ + L.o_basis_;
+    for (int k = 0; k < 4; ++k) {
+        W.cwT[k] = L.d_w_ + L.o_cw_[k];
+        W.cb[k] = L.d_w_ + L.o_cb_[k];
+    }
+    W.w_ihT = L.d_w_ + L.o_wih_;
+    W.bg = L.d_w_ + L.o_bg_;
+    hipLaunchKernelGGL(silero_frontend_kernel, dim3((unsigned)total), dim3(256), 0, L.st_, (const float *)L.d_wav_, W, L.d_gx_, (int)total);
+    MW_HIP(hipGetLastError());
+    hipLaunchKernelGGL(silero_lstm_kernel, dim3(n), dim3(512), 0, L.st_, (const float *)L.d_gx_, (const float *)(L.d_w_ + L.o_whh_),
+                       (const float *)(L.d_w_ + L.o_outw_), L.out_b_, StreamDesc{nullptr, 0, 0}, (const StreamDesc *)L.d_desc_, L.d_probs_);
+    MW_HIP(hipGetLastError());
+    float *h_probs = L.h_pin_ + (size_t)L.cap_ * WINDOW;
+    MW_HIP(hipMemcpyAsync(h_probs, L.d_probs_, (size_t)total * sizeof(float), hipMemcpyDeviceToHost, L.st_));
+    MW_HIP(hipStreamSynchronize(L.st_));
+    at = 0;
+    for (int i = 0; i < n; ++i) {
+        if (items[i].n_windows) memcpy(items[i].probs, h_probs + at, (size_t)items[i].n_windows * sizeof(float));
+        at += items[i].n_windows;
+    }
 }
 
 void SileroVad::get_state(float *hc256) {

@@ -28,6 +28,16 @@ struct SileroWeights {
 // Host only (no GPU needed).  Throws std::runtime_error naming what is wrong with the file.
 SileroWeights load_silero_onnx(const std::string &path);
 
+class SileroVad;
+// one stream's share of a batched pass (SileroVad::process_batch)
+struct SileroBatchItem {
+    SileroVad *vad;      // the stream's network state (all items of a batch: the same weights, the same device)
+    const float *wav;    // host
+    int n_windows;
+    bool reset;
+    float *probs;        // host, n_windows
+};
+
 class SileroVad {
 public:
     static constexpr int WINDOW = 512;  // 32 ms at 16 kHz (silero-vad-onnx.cpp:333-335)
@@ -39,6 +49,11 @@ public:
     // previous call unless `reset` (VadIterator::reset_states(true)).
     void process(const float *wav, int n_windows, bool reset, float *probs);
     void get_state(float *hc256);  // h[128], c[128]: the model's `state` tensor (tests)
+    // The windows of SEVERAL streams in one pass (SURVEY.md §8 f2 "batched across streams"): one front-end launch over all
+    // windows, one recurrent launch with a workgroup per stream, each on its own state.  Same results as process() per
+    // stream.  The handles must not be in use by another thread during the call; launches go on items[0].vad's stream.
+    static void process_batch(const SileroBatchItem *items, int n);
+    static constexpr int MAX_BATCH_STREAMS = 256;
 
 private:
     void reserve(int n_windows);
@@ -50,6 +65,8 @@ private:
     float *d_wav_ = nullptr, *d_gx_ = nullptr, *d_probs_ = nullptr, *d_state_ = nullptr;
     float *h_pin_ = nullptr;  // pinned staging: windows in, probabilities out
     int cap_ = 0;
+    unsigned long long weights_id_ = 0;  // FNV-1a over the weights: a batch shares the leader's copy
+    void *d_desc_ = nullptr, *h_desc_ = nullptr;  // per-stream descriptors of a batched pass (device, pinned host)
 };
 
 }  // namespace mw

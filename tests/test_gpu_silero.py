@@ -72,6 +72,33 @@ def test_state_carries_between_calls_and_reset_clears_it(pkg, model):
         vad.close()
 
 
+def test_batched_streams_equal_single_stream_calls(pkg, model):
+    # SURVEY.md §8 f2 "batched across streams": the windows of several streams in one front-end launch + one recurrent launch
+    # with a workgroup per stream; per stream exactly what lv_silero_process returns, state carried per stream
+    path, _ = model
+    n = 9
+    solo = [pkg.SileroVad(path) for _ in range(n)]
+    together = [pkg.SileroVad(path) for _ in range(n)]
+    try:
+        rng = np.random.RandomState(5)
+        for rnd in range(3):
+            wavs = [speechlike(100 + 10 * rnd + i, float(rng.uniform(0.2, 3.0))) for i in range(n)]
+            wavs[2] = wavs[2][:100]                              # less than a window: nothing to do for this stream
+            resets = [rnd == 0 or bool(rng.randint(0, 2)) for _ in range(n)]
+            want = [v.process(w, reset=r) for v, w, r in zip(solo, wavs, resets)]
+            got = pkg.silero_process_batch(together, wavs, resets)
+            for i in range(n):
+                assert np.array_equal(got[i], want[i]), (rnd, i)
+                assert np.array_equal(together[i].state(), solo[i].state()), (rnd, i)
+        assert any(len(w) for w in want)
+        # a stream twice in one batch, or streams of different models, are refused
+        with pytest.raises(RuntimeError):
+            pkg.silero_process_batch([together[0], together[0]], [wavs[0], wavs[1]], [True, True])
+    finally:
+        for v in solo + together:
+            v.close()
+
+
 def test_vad_iterator_on_the_network_matches_the_restatement(pkg, model):
     path, w = model
     f = pkg.Filter()

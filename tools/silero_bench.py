@@ -38,6 +38,21 @@ def main():
         dt = (time.time() - t0) / reps
         print(f"{seconds:5.1f} s of audio ({n // 512:3d} windows): {dt * 1e3:.3f} ms per call from host PCM = {seconds / dt:,.0f} x real time")
     vad.close()
+    # 64 streams, one second of new audio each (what 64 sources hand in per second): one call each vs one batched pass
+    vads = [pkg.SileroVad(path) for _ in range(64)]
+    wavs = [x[i * 1000:i * 1000 + 16000] for i in range(64)]
+    for mode in ("one call per stream", "one batched pass"):
+        for rep in range(4):
+            if rep == 1:
+                t0 = time.time()
+            if mode.startswith("one call"):
+                for v, w in zip(vads, wavs):
+                    v.process(w)
+            else:
+                pkg.silero_process_batch(vads, wavs, [True] * 64)
+        print(f"64 streams x 1 s, {mode}: {(time.time() - t0) / 3 * 1e3:.2f} ms")
+    for v in vads:
+        v.close()
 
 
 if __name__ == "__main__":
