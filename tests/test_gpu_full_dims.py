@@ -1,7 +1,7 @@
 """GPU: the benchmarked configurations at their OWN dimensions against the oracle, teacher-forced.
 
   BASELINE configs[2]  Whisper large-v3 dims (d=1280, 32+32 layers, 128 mel bins, vocab 51866), bf16, 5 rows per step
-  BASELINE configs[3]  large-v3-turbo dims (4 decoder layers), bf16, 8 concurrent contexts on one upload of the weights
+  BASELINE configs[3]  large-v3-turbo dims (4 decoder layers), bf16, 64 concurrent contexts on one upload of the weights
 
 Seeded synthetic weights in the GGML container (tools/synth_large; no checkpoints exist offline).  The bf16 engine cannot be
 token-exact against the fp32 oracle, so the comparison is teacher-forced: the ORACLE's token histories are fed to both
@@ -108,11 +108,12 @@ def test_large_v3_dims_bf16_teacher_forced_beam5_rows(pkg, big_model):
     _teacher_forced(pkg, big_model("large-v3"), n_rows=5, steps=8)
 
 
-def test_turbo_dims_bf16_teacher_forced_and_8_shared_weight_contexts(pkg, big_model):
+def test_turbo_dims_bf16_teacher_forced_and_64_shared_weight_contexts(pkg, big_model):
     path = big_model("large-v3-turbo")
     _teacher_forced(pkg, path, n_rows=5, steps=8)
-    # configs[3]: concurrent streams on ONE upload of the weights give each stream the tokens it gets alone
-    n_streams, steps = 8, 24
+    # configs[3] at its own size: 64 concurrent streams on ONE upload of the weights, decode steps and encoder windows of
+    # different streams batched by the hub, give each stream the tokens it gets alone
+    n_streams, steps = 64, 24
     clips = [ggml_io.synth_pcm(100 + i, 30.0) for i in range(n_streams)]
     first = pkg.Engine(path, precision=pkg.PRECISION_BF16)
     engs = [first] + [pkg.Engine(path, precision=pkg.PRECISION_BF16, share=first) for _ in range(n_streams - 1)]
@@ -125,9 +126,11 @@ def test_turbo_dims_bf16_teacher_forced_and_8_shared_weight_contexts(pkg, big_mo
         for i, e in enumerate(engs):
             assert e.full(params[i], clips[i]) == 0
             solo.append(e.token_ids())
-        assert all(len(t) >= 4 for t in solo)                # (a timestamp token may close the segment before the forced length)
+        # (random weights: a timestamp token may close the segment long before the forced length)
+        assert all(len(t) >= 1 for t in solo) and sum(len(t) >= 4 for t in solo) >= n_streams // 2
         assert len({tuple(t) for t in solo}) > 1          # the clips do lead to different transcripts
         out, errs = [None] * n_streams, []
+        s0 = first.hub_stats()
 
         def work(i):
             try:
@@ -144,6 +147,10 @@ def test_turbo_dims_bf16_teacher_forced_and_8_shared_weight_contexts(pkg, big_mo
             t.join()
         assert not errs, errs
         assert out == solo
+        s1 = first.hub_stats()
+        d_steps, d_rows, d_req, d_pass, d_win = (s1[k] - s0[k] for k in range(5))
+        print(f"hub, 64 turbo streams: {d_rows / d_steps:.1f} rows per step, {d_win / d_pass:.1f} windows per encoder pass")
+        assert d_rows / d_steps > 4 and d_win / d_pass > 2   # the streams did share steps and passes
     finally:
         for e in engs[1:] + engs[:1]:
             e.close()
