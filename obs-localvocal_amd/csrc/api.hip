@@ -17,6 +17,8 @@ std::mutex g_log_mutex;
 thread_local std::string g_last_error;
 }  // namespace
 
+void set_last_error(const std::string &msg) { g_last_error = msg; }  // what mw_last_error() returns on this thread
+
 void log_msg(int level, const char *fmt, ...) {
     char buf[1024];
     va_list ap;

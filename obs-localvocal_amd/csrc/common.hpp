@@ -15,6 +15,7 @@ namespace mw {
 
 // ---- logging (whisper_log_set; /root/reference/src/whisper-utils/whisper-processing.cpp:46-57) ----
 void log_msg(int level, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+void set_last_error(const std::string &msg);  // thread-local slot behind mw_last_error()
 constexpr int LOG_ERROR = 2, LOG_WARN = 3, LOG_INFO = 4, LOG_DEBUG = 5;
 
 struct hip_error : std::runtime_error {

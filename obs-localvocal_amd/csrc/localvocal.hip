@@ -237,8 +237,10 @@ template <typename F> int lv_guard(F &&fn) {
         return fn();
     } catch (const std::exception &e) {
         mw::log_msg(kLogError, "localvocal: %s\n", e.what());
+        mw::set_last_error(e.what());
         return -100;
     } catch (...) {
+        mw::set_last_error("unknown error");
         return -101;
     }
 }
