@@ -133,6 +133,51 @@ def test_segmentation_driven_by_the_network_matches_the_restatement(pkg, model, 
         assert (t0, t1, vs) == (r.t0, r.t1, r.vad_state) and np.array_equal(pcm, r.pcm)
 
 
+def test_worker_thread_with_the_network_as_its_vad(pkg, model, model_file):
+    # whisper_loop end to end (audio tap -> vad_based_segmentation on the device network -> run_whisper_inference on the
+    # same GPU): the requests the worker sends are those of the restatement driven by the restated network
+    import time
+    path, w = model
+    f = pkg.Filter(precision=pkg.PRECISION_FP32)
+    requests, texts = [], []
+    f.set_callbacks(on_text=lambda d: texts.append(d), on_request=lambda pcm, t0, t1, vs: requests.append((pcm, t0, t1, vs)))
+    try:
+        assert f.set_silero_model(path) == 0
+        f.setup_audio(16000, 1)
+        f.L.lv_filter_set_vad_mode(f.f, sg.VAD_MODE_ACTIVE)
+        f.L.lv_filter_set_partial(f.f, 0, 1100)
+        f.L.lv_filter_set_segment_duration(f.f, 3000)
+        f.L.lv_filter_set_thresholds(f.f, 0.0, 1e6)
+        f.params.temperature_inc = 0.0
+        assert f.start(model_file("micro.en")) == 0
+        assert f.L.lv_filter_vad_is_silero(f.f) == 1          # start_whisper_thread_with_path built the same iterator
+        orc = sg.SegmenterOracle(vad_mode=sg.VAD_MODE_ACTIVE, partial_transcription=False, partial_latency=1100, segment_duration=3000,
+                                 vad=sg.VadIteratorOracle(prob_source=so.SileroOracle(w)))
+        x = speechlike(3, 10.0)
+
+        def wait(cond, timeout_s):
+            t0 = time.time()
+            while time.time() - t0 < timeout_s:
+                if cond():
+                    return True
+                time.sleep(0.01)
+            return False
+
+        for i in range(0, len(x), 4000):   # lock-step with the worker, as the offline harness feeds (one pass per packet)
+            ts = 1_000_000_000 + i * 1_000_000_000 // 16000
+            assert f.push_packet([x[i:i + 4000]], ts) == 0
+            orc.push_packet(x[i:i + 4000], ts)
+            orc.step()
+            assert wait(lambda: f.L.lv_filter_input_bytes(f.f) == 0, 20.0)
+            assert wait(lambda: len(requests) >= len(orc.requests) and len(texts) >= len(orc.requests), 30.0)
+        f.stop()
+        assert len(orc.requests) >= 2 and len(requests) == len(orc.requests) == len(texts)
+        for (pcm, t0, t1, vs), r in zip(requests, orc.requests):
+            assert (t0, t1, vs) == (r.t0, r.t1, r.vad_state) and np.array_equal(pcm, r.pcm)
+    finally:
+        f.close()
+
+
 def test_a_file_that_is_not_the_graph_is_refused(pkg, model, tmp_path):
     path, _ = model
     cut = str(tmp_path / "cut.onnx")
