@@ -1,5 +1,6 @@
 """Development aid: time the Silero VAD pass (csrc/silero_vad.hip) on buffers of the sizes vad_based_segmentation sends
-(new audio since the last step: 0.1 - 10 s) and print the deviation from the CPU restatement on synthetic weights."""
+(new audio since the last step: 0.1 - 10 s), one stream and 64 streams, on synthetic weights (the deviation from the CPU
+restatement is what tests/test_gpu_silero.py checks and prints)."""
 import importlib
 import os
 import sys
@@ -9,7 +10,7 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import silero_vad_oracle as so  # noqa: E402  (checker only)
+from tools import silero_synth as so  # noqa: E402
 
 pkg = importlib.import_module("obs-localvocal_amd")
 
@@ -22,11 +23,7 @@ def main():
     rng = np.random.default_rng(0)
     x = (0.05 * rng.standard_normal(16000 * 10)).astype(np.float32)
     x[16000 * 3:16000 * 5] *= 0.01
-    got = vad.process(x)
-    t0 = time.time()
-    want = so.SileroOracle(w).process(x)
-    t_cpu = time.time() - t0
-    print(f"max |gpu - restatement| = {np.abs(got - want).max():.2e} over {len(got)} windows; restatement {t_cpu * 1e3:.0f} ms")
+    vad.process(x)
     for seconds in (0.1, 0.5, 1.0, 3.0, 10.0):
         n = int(seconds * 16000)
         for _ in range(3):

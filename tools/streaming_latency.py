@@ -2,11 +2,12 @@
 """SURVEY.md §8(d) configuration 5: streaming partial transcription latency through the LocalVocal worker.
 
 A 64 s synthetic "speech-like" signal (noise bursts of 0.5-2.5 s separated by 0.3-1 s of near-silence, seed 7) is fed
-to the worker thread in real-time-ordered 10 ms packets (lock-step, no sleeping); VAD mode ACTIVE with the energy gate
-standing in for Silero, partial transcription every partial_latency = 1100 ms
+to the worker thread in real-time-ordered 10 ms packets (lock-step, no sleeping); VAD mode ACTIVE with the Silero network
+on the GPU (`--vad silero`, default: a synthetic model file of the real graph's shapes whose probability follows the
+signal's energy, tools/silero_synth.py; `--vad gate`: the energy gate), partial transcription every partial_latency = 1100 ms
 (transcription-filter-properties.cpp:710); beam search as the plugin defaults.  Reported: per-call latency of
 run_whisper_inference (request observed -> result callback), p50 / p95 / max, split into partial and final calls.
-Weights: seeded synthetic GGML file of the chosen dims (bf16; the fp8 variant of the configuration is not built yet);
+Weights: seeded synthetic GGML file of the chosen dims (bf16, or `--precision fp8`: e4m3 decoder weights);
 decode length forced to `--tokens` per call (random weights would stop after 1-2 tokens).
 """
 from __future__ import annotations
@@ -21,7 +22,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from tools import ggml_io, synth_large  # noqa: E402
+from tools import ggml_io, silero_synth, synth_large  # noqa: E402
 from tools.offline_test import load_package  # noqa: E402
 
 
@@ -43,6 +44,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=64.0)
     ap.add_argument("--tokens", type=int, default=12)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp8"])
+    ap.add_argument("--vad", default="silero", choices=["silero", "gate"])
     ap.add_argument("--model-dir", default=os.environ.get("MI355_WHISPER_BENCH_DIR", "/tmp/mi355_whisper_bench"))
     a = ap.parse_args()
     pkg = load_package()
@@ -61,6 +63,11 @@ def main():
             lat.append((time.perf_counter() - t_req.pop("t"), t_req["vs"], t_req["n"]))
 
     try:
+        if a.vad == "silero":
+            vad_path = os.path.join(a.model_dir, "silero_synth_s11.onnx")
+            if not os.path.exists(vad_path):
+                silero_synth.write_onnx(vad_path, silero_synth.synth_weights(11))
+            assert f.set_silero_model(vad_path) == 0
         f.setup_audio(16000, 1)
         f.L.lv_filter_set_vad_mode(f.f, pkg.VAD_MODE_ACTIVE)
         f.L.lv_filter_set_partial(f.f, 1, 1100)
@@ -86,7 +93,7 @@ def main():
         return {"calls": int(len(v)), "p50_ms": round(float(np.percentile(v, 50)), 2), "p95_ms": round(float(np.percentile(v, 95)), 2),
                 "max_ms": round(float(v[-1]), 2)} if len(v) else {"calls": 0}
 
-    out = {"workload": f"{a.model} {'e4m3 decoder weights, bf16 activations' if a.precision == 'fp8' else 'bf16'} beam 5, {a.seconds:.0f} s speech-like stream, VAD active (energy gate), partials every 1100 ms, "
+    out = {"workload": f"{a.model} {'e4m3 decoder weights, bf16 activations' if a.precision == 'fp8' else 'bf16'} beam 5, {a.seconds:.0f} s speech-like stream, VAD active ({'Silero network on the GPU, synthetic weights' if a.vad == 'silero' else 'energy gate'}), partials every 1100 ms, "
                        f"{a.tokens} forced tokens per call",
            "all": stats([l for l, _, _ in lat]), "partial": stats([l for l, vs, _ in lat if vs == 3]),
            "final": stats([l for l, vs, _ in lat if vs != 3]),
