@@ -28,7 +28,7 @@ def _new_filter(pkg, texts, requests):
     f = pkg.Filter(precision=pkg.PRECISION_FP32)
     f.set_callbacks(on_text=lambda d: texts.append(d), on_request=lambda pcm, t0, t1, vs: requests.append((pcm, t0, t1, vs)))
     f.setup_audio(SR, 1)
-    f.L.lv_filter_set_vad_mode(f.f, 0)             # VAD_MODE_DISABLED: every pass sends what is buffered
+    f.L.lv_filter_set_vad_mode(f.f, 0)             # VAD_MODE_ACTIVE on the energy gate
     f.L.lv_filter_set_thresholds(f.f, 0.0, 1e6)   # random weights: accept every sentence
     f.L.lv_filter_set_max_sub_duration(f.f, 60000)
     f.params.temperature_inc = 0.0
@@ -70,13 +70,20 @@ def test_update_whisper_model_lifecycle(pkg, model_file):
 
         # A -> B while the worker is parked in its 250 ms wait: shutdown frees the context under the context mutex, wakes
         # and joins the worker, the new worker starts on B; prompt (no 250 ms multiples stacked up, no deadlock)
-        # (really parked: with VAD disabled an idle pass flushes what is left in the whisper buffer, vad-processing.cpp:133-143 —
-        # one more inference, up to 250 ms after the input ran dry; were it to land on B's fresh context it would advance that
-        # context's generator and prompt before the comparison below)
-        idle = lambda: f.L.lv_filter_input_bytes(f.f) == 0 and f.L.lv_filter_whisper_bytes(f.f) == 0
-        assert _wait(idle, 20.0)
-        time.sleep(0.8)
-        assert idle()
+        # (really parked: no packet waiting and no inference in flight — every request has had its result — for three worker
+        # periods in a row; VAD is active here, so a burst still open at the end of the feed may stay in the whisper buffer)
+        def parked():
+            return f.L.lv_filter_input_bytes(f.f) == 0 and len(requests) == len(texts)
+
+        def parked_for(seconds):
+            t_end = time.time() + seconds
+            while time.time() < t_end:
+                if not parked():
+                    return False
+                time.sleep(0.02)
+            return True
+
+        assert _wait(lambda: parked() and parked_for(0.8), 30.0)
         f.set_setting("whisper_model_path", "Micro B")
         t0 = time.time()
         assert f.update_model() == 0
