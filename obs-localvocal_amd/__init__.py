@@ -17,7 +17,9 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmi355_whisper.so")
+# MI355_WHISPER_LIB: another BUILD of this same library (development A/B runs of two kernel variants on one box); no other
+# library can stand in, every symbol of include/*.h is bound below
+LIB_PATH = os.environ.get("MI355_WHISPER_LIB") or os.path.join(_HERE, "libmi355_whisper.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 PRECISION_BF16 = 0
@@ -596,7 +598,8 @@ class Filter:
         def det(d):
             d = d.contents
             return dict(result=d.result, text=(d.text or b""), start=d.start_timestamp_ms, end=d.end_timestamp_ms,
-                        n_tokens=d.n_tokens, language=(d.language or b"").decode())
+                        n_tokens=d.n_tokens, language=(d.language or b"").decode(),
+                        tokens=[(d.tokens[i].id, d.tokens[i].p) for i in range(d.n_tokens)])
         self._cb_text = LV_TEXT_CB((lambda u, d: on_text(det(d))) if on_text else 0)
         self._cb_chunk = LV_CHUNK_CB((lambda u, pcm, n, vs, d: on_chunk(np.ctypeslib.as_array(pcm, (n,)).copy(), vs, det(d)))
                                      if on_chunk else 0)

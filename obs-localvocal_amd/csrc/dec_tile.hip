@@ -615,20 +615,43 @@ __device__ __forceinline__ void self_attn_lean(const float *q, const bf16_t *kc,
     }
 }
 
-constexpr int CPART = 66;
+// One partial softmax record = (max, sum, 64 partial outputs) of one (row, head, split): 66 floats, padded to 96 = three
+// 128-byte lines of its own (the buffer comes from hipMalloc: 256-byte aligned).  No line is ever shared by the records of two
+// workgroups, so a combiner that runs early on some XCD cannot pull a line into that XCD's L2 that another split has yet to
+// write (at 66 floats the last split of head h and split 0 of head h + 1 shared a line).
+constexpr int CPART = CROSS_PART_STRIDE;
+static_assert(CPART >= 66 && CPART % 32 == 0, "a partial record starts on a 128-byte line");
 
 // tail of a cross-attention work item: count this split of head h; the last one to arrive combines the partial
 // softmax records of all splits (fixed split order) into the output rows.  Rows row0 .. row0 + n - 1 of the step
 // (row0 = 0, cnt = h for a single context; the request's rows and counter in a batched step).
+//
+// Hand-off (MI355X_MICROARCH.md, "Valid forms"; cdna_hip_programming.md Guideline 16, R1 + consumer recipe):
+//   producers  — every record byte leaves by an sc1 (write-through) store (st_agent), EVERY storing wave drains its stores
+//                (s_waitcnt vmcnt(0) as inline asm: the compiler cannot drop it), the workgroup barrier, then ONE lane's
+//                returning agent-scope fetch_add on the head's counter;
+//   consumer   — the workgroup whose add returned splits - 1: that lane runs ONE agent-scope acquire (buffer_inv sc1: this
+//                CU's L1 may hold lines of the record buffer from an earlier workgroup), waits vmcnt(0) so the barrier
+//                below is not passed before the invalidate has completed, raises the LDS flag; after the barrier every
+//                wave reads the records with plain loads.
+// Measured against the other valid form for one workgroup per CU (every record load an sc1 load, no invalidate; the
+// kernel's LDS raised above 80 KB to guarantee the residency): 157.0 / 157.5 vs 157.2 / 157.1 audio-s/s, 9.49 / 9.68 vs
+// 9.47 / 9.66 us per launch, interleaved runs on one box — no difference, so the form that holds for any residency is
+// the only one kept.  The counter is reset by the combiner for the next launch AFTER its loads were issued (nobody adds
+// to it again in this launch; the kernel boundary publishes the store).
 template <int NB, typename OT>
 __device__ __forceinline__ void cross_count_and_combine(const float *part, OT *out, unsigned *head_cnt, unsigned *flag, int row0, int n,
                                                         int H, int d, int h, int cnt, int splits) {
     const int tid = threadIdx.x;
-    __syncthreads();  // partial stores acknowledged (vmcnt(0)) before this split is counted
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's record stores are acknowledged
+    __syncthreads();                                   // ... and so are every other wave's, before the split is counted
     if (tid == 0) {
         const unsigned old = __hip_atomic_fetch_add(&head_cnt[cnt], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned last = old == (unsigned)splits - 1;
-        if (last) __hip_atomic_store(&head_cnt[cnt], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         *flag = last;
     }
     lds_sync();
@@ -649,6 +672,7 @@ __device__ __forceinline__ void cross_count_and_combine(const float *part, OT *o
                 mlv[sidx] = *reinterpret_cast<const float2 *>(ps);
                 ov[sidx] = ps[2 + e];
             }
+            if (it == 0 && tid == 0) __hip_atomic_store(&head_cnt[cnt], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
             float M = -INFINITY;
 #pragma unroll
             for (int sidx = 0; sidx < CROSS_SPLITS_MAX; ++sidx) M = fmaxf(M, sidx < splits ? mlv[sidx].x : -INFINITY);

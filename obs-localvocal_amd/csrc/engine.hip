@@ -116,7 +116,7 @@ std::unique_ptr<Context> create_context_impl(const unsigned char *data, size_t s
     dev_alloc(c->d_q, TC * d);
     dev_alloc_bytes(c->d_attd, TC * d * 4);
     dev_alloc_bytes(c->d_ffd, TC * 4 * d * 4);
-    dev_alloc(c->d_part, TC * H * CROSS_SPLITS_MAX * 66);
+    dev_alloc(c->d_part, TC * H * CROSS_SPLITS_MAX * CROSS_PART_STRIDE);
     dev_alloc(c->d_logits, (size_t)LOGIT_ROWS * nv);
     dev_alloc(c->d_work, process_logits_work_floats(LOGIT_ROWS, nv));
     dev_alloc(c->d_suppress, nv);
@@ -215,7 +215,7 @@ std::shared_ptr<Hub> create_hub(const Model &m, int device, bool use_graphs) {
         dev_alloc(ln.d_q, R * d);
         dev_alloc_bytes(ln.d_attd, R * d * 2);
         dev_alloc_bytes(ln.d_ffd, R * 4 * d * 2);
-        dev_alloc(ln.d_part, R * H * CROSS_SPLITS_MAX * 66);
+        dev_alloc(ln.d_part, R * H * CROSS_SPLITS_MAX * CROSS_PART_STRIDE);
         dev_alloc(ln.d_logits, R * nv);
         dev_alloc(ln.d_work, process_logits_work_floats((int)R, (int)nv));
         dev_alloc(ln.d_suppress, nv);
@@ -724,6 +724,9 @@ void pcm_to_mel(Context &c, const float *pcm, int n_samples, bool pcm_on_device)
                          n_active, n_mel, 1, c.d_gmax, c.st);
     c.n_len = n_len;
     c.n_len_org = 1 + (n_samples + MEL_N_FFT / 2 - MEL_N_FFT) / MEL_HOP;
+    // the hub's encoder lane reads d_mel on ITS stream: it must wait for these kernels (Hub::run_encode waits on ev_ready
+    // only when the flag is set; after a context's first call the last hub step had cleared it)
+    c.st_dirty = true;
     c.tm.mel_ms += now_ms() - t0;
 }
 

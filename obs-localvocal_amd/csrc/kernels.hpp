@@ -97,6 +97,9 @@ void launch_convert(const float *src, void *dst, DType dt, size_t n, hipStream_t
 constexpr int DEC_MAX_ROWS = 8;      // activation rows one weight pass serves
 constexpr int KV_SLOTS = 8;          // physical self-KV slots per stream (= WHISPER_MAX_DECODERS)
 constexpr int CROSS_SPLITS_MAX = 16;
+// floats per partial softmax record of the decode cross-attention (dec_tile.hip: 66 used, padded to whole 128-byte lines;
+// dec.hip packs 66): what the d_part buffers are sized with
+constexpr int CROSS_PART_STRIDE = 96;
 
 // A batched step: up to STEP_MAX_ROWS rows that ride in M of one 16-row MFMA tile, taken from up to STEP_MAX_GROUPS
 // requests (one request = the rows of one stream context: its beams, or the tokens of a short prompt).  Everything that

@@ -206,7 +206,6 @@ struct lv_filter {
     DetectionResultWithText last;
     lv_settings settings;
     vad_state vs = {false, 0, 0, 0};
-    float gate_db = -40.0f, slope_db = 3.0f, vad_threshold = 0.5f;
     lv_text_cb on_text = nullptr;
     lv_chunk_cb on_chunk = nullptr;
     lv_request_cb on_request = nullptr;
@@ -227,8 +226,13 @@ lv_detection flatten(const DetectionResultWithText &r) {
     return d;
 }
 
+// (Re)builds the filter's VAD from its configuration.  The worker thread uses gf.vad outside whisper_ctx_mutex
+// (segmentation.hip), so the object is never replaced while a worker exists: callers on a running filter get an error and
+// the new configuration takes effect at the next start (start_whisper_thread_with_path -> initialize_vad).
 void make_vad(lv_filter *f) {
-    f->gf.vad.reset(build_vad(f->gf.silero_vad_model_file.c_str(), f->gf.gpu_device, f->gate_db, f->slope_db, f->vad_threshold));
+    if (f->gf.whisper_thread.joinable()) throw std::runtime_error("the VAD cannot be rebuilt while the worker thread is running");
+    f->gf.vad.reset(build_vad(f->gf.silero_vad_model_file.c_str(), f->gf.gpu_device, f->gf.vad_gate_db, f->gf.vad_gate_slope_db,
+                              f->gf.vad_threshold));
 }
 
 // every entry below returns an error code instead of letting an exception cross the C boundary
@@ -310,8 +314,8 @@ int lv_filter_apply_settings(lv_filter *f) {
         gf.language_storage = language_selected ? sel : "auto";
         gf.whisper_params.language = gf.language_storage.c_str();
         gf.whisper_params.detect_language = !language_selected;
-        f->vad_threshold = (float)f->settings.get_double("vad_threshold");
-        if (gf.vad) gf.vad->set_threshold(f->vad_threshold);
+        gf.vad_threshold = (float)f->settings.get_double("vad_threshold");
+        if (gf.vad) gf.vad->set_threshold(gf.vad_threshold);  // a float store, as transcription-filter.cpp:447-448 does on a live filter
         return 0;
     });
 }
@@ -343,9 +347,13 @@ void lv_filter_enable_audio_chunks_callback(lv_filter *f, int enable) {
 }
 void lv_filter_set_vad_gate(lv_filter *f, float gate_db, float slope_db, float threshold) {
     if (!f) return;
-    f->gate_db = gate_db;
-    f->slope_db = slope_db > 0.0f ? slope_db : 3.0f;
-    f->vad_threshold = threshold;
+    f->gf.vad_gate_db = gate_db;
+    f->gf.vad_gate_slope_db = slope_db > 0.0f ? slope_db : 3.0f;
+    f->gf.vad_threshold = threshold;
+    if (f->gf.whisper_thread.joinable()) {  // live worker: only the threshold changes now, the gate shape at the next start
+        if (f->gf.vad) f->gf.vad->set_threshold(threshold);
+        return;
+    }
     try {
         make_vad(f);
     } catch (...) {
@@ -437,8 +445,7 @@ int lv_filter_start(lv_filter *f, const char *model_path) {
                                        f->gf.silero_vad_model_file.empty() ? "silero-vad/silero_vad.onnx" : f->gf.silero_vad_model_file.c_str());
         if (f->gf.whisper_context == nullptr) return -3;
         f->gf.whisper_model_path = model_path;
-        make_vad(f);  // keep the gate configured through lv_filter_set_vad_gate
-        return 0;
+        return 0;  // initialize_vad built the VAD from gf's gate / threshold configuration before the worker started
     });
 }
 void lv_filter_stop(lv_filter *f) {
@@ -493,8 +500,7 @@ int lv_filter_update_model(lv_filter *f) {
     if (!f) return -1;
     return lv_guard([&] {
         f->gf.context = &f->settings;
-        update_whisper_model(&f->gf);
-        if (f->gf.whisper_context != nullptr && f->gf.vad) make_vad(f);  // keep the gate configured through lv_filter_set_vad_gate
+        update_whisper_model(&f->gf);  // a restart rebuilds the VAD itself (initialize_vad, before the new worker exists)
         return f->gf.whisper_context != nullptr ? 0 : 1;
     });
 }
@@ -514,6 +520,7 @@ int lv_filter_model_state(lv_filter *f, char *model_path, size_t n_path, char *f
 int lv_vad_speech_timestamps(lv_filter *f, const float *pcm, size_t n, int reset_state, int *pairs, int cap) {
     if (!f || (!pcm && n) || (!pairs && cap > 0)) return -1;
     return lv_guard([&] {
+        if (f->gf.whisper_thread.joinable()) throw std::runtime_error("lv_vad_speech_timestamps: the worker thread owns the VAD");
         if (!f->gf.vad) make_vad(f);
         std::vector<float> wav(pcm, pcm + n);
         f->gf.vad->process(wav, reset_state != 0);
@@ -528,6 +535,10 @@ int lv_vad_speech_timestamps(lv_filter *f, const float *pcm, size_t n, int reset
 int lv_filter_set_silero_model(lv_filter *f, const char *path) {
     if (!f) return -1;
     return lv_guard([&] {
+        if (f->gf.whisper_thread.joinable()) {
+            mw::set_last_error("lv_filter_set_silero_model: stop the filter first (the worker thread is using its VAD)");
+            return -2;
+        }
         f->gf.silero_vad_model_file = path ? path : "";
         make_vad(f);  // throws (-> -100, mw_last_error) when the file is there but is not a Silero v5 graph
         return f->gf.vad->has_batch_source() ? 0 : 1;

@@ -229,6 +229,9 @@ struct transcription_filter_data {
 
     /* VAD */
     std::unique_ptr<VadIterator> vad;
+    // what initialize_vad builds it with (the reference passes 0.5 and the UI sets the threshold afterwards,
+    // vad-processing.cpp:473-474); the gate shape only matters while the energy gate stands in for the Silero file
+    float vad_gate_db = -40.0f, vad_gate_slope_db = 3.0f, vad_threshold = 0.5f;
 
     float sentence_psum_accept_thresh = 0.4f;
     int vad_mode = VAD_MODE_ACTIVE;

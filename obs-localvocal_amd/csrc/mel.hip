@@ -43,9 +43,42 @@ constexpr int NH = MEL_N_FFT / 2;                                   // 200-point
 struct cpx {
     float x, y;
 };
-__device__ __forceinline__ cpx cadd(cpx a, cpx b) { return {a.x + b.x, a.y + b.y}; }
-__device__ __forceinline__ cpx csub(cpx a, cpx b) { return {a.x - b.x, a.y - b.y}; }
-__device__ __forceinline__ cpx cmul(cpx a, cpx b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+// An empty asm statement the optimiser cannot look through: the re and im parts of a complex value that passed through it
+// are no longer "adjacent scalar operations" for hipcc's SLP vectoriser, so no packed-f32 instruction (v_pk_*_f32) is
+// formed from them whatever flags the file is built with (see the note on mel_frames_kernel below).
+#ifndef MEL_OPQ_FFT
+#define MEL_OPQ_FFT 1
+#endif
+#ifndef MEL_OPQ_PW
+#define MEL_OPQ_PW 1
+#endif
+__device__ __forceinline__ float opaque(float v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ cpx fft_opq(cpx a) {
+#if MEL_OPQ_FFT
+    a.y = opaque(a.y);
+#endif
+    return a;
+}
+__device__ __forceinline__ cpx pw_opq(cpx a) {
+#if MEL_OPQ_PW
+    a.x = opaque(a.x);
+    a.y = opaque(a.y);
+#endif
+    return a;
+}
+__device__ __forceinline__ cpx cadd(cpx a, cpx b) { return fft_opq({a.x + b.x, a.y + b.y}); }
+__device__ __forceinline__ cpx csub(cpx a, cpx b) { return fft_opq({a.x - b.x, a.y - b.y}); }
+__device__ __forceinline__ cpx cmul(cpx a, cpx b) {
+#if MEL_OPQ_FFT || MEL_OPQ_PW
+    const float p2 = opaque(a.y * b.y), p4 = opaque(a.y * b.x);  // (the other two products contract into the fma)
+    return fft_opq({a.x * b.x - p2, a.x * b.y + p4});
+#else
+    return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+#endif
+}
 __device__ __forceinline__ cpx cscale(cpx a, float s) { return {a.x * s, a.y * s}; }
 __device__ __forceinline__ cpx mul_neg_i(cpx a) { return {a.y, -a.x}; }  // a * (-i)
 __device__ __forceinline__ cpx mul_pos_i(cpx a) { return {-a.y, a.x}; }  // a * (+i)
@@ -144,7 +177,7 @@ __global__ __launch_bounds__(256) void mel_frames_kernel(const float *__restrict
         // windowed samples packed as z[n] = x[2n] + i x[2n+1]
         for (int n = lane; n < NH; n += 64) {
             const int o = fl * MEL_HOP + 2 * n;
-            A[n] = cpx{L.pcm[o] * L.hann[2 * n], L.pcm[o + 1] * L.hann[2 * n + 1]};
+            A[n] = fft_opq(cpx{L.pcm[o] * L.hann[2 * n], L.pcm[o + 1] * L.hann[2 * n + 1]});
         }
         __syncthreads();
         // stage 1: radix 5, Ns = 1 (no twiddles)
@@ -190,14 +223,22 @@ __global__ __launch_bounds__(256) void mel_frames_kernel(const float *__restrict
         for (int k = lane; k < MEL_N_FREQ + 3; k += 64) {
             float p = 0.0f;
             if (k < MEL_N_FREQ) {
-                const cpx zk = B[k % NH];
-                const cpx zn = B[(NH - k) % NH];
-                const cpx e = {0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y)};
-                const cpx d = {zk.x - zn.x, zk.y + zn.y};           // Zk - conj(Zn)
-                const cpx o = {0.5f * d.y, -0.5f * d.x};            // d / (2i)
+                cpx zk = B[k % NH];
+                cpx zn = B[(NH - k) % NH];
+#if MEL_OPQ_PW
+                zk.y = opaque(zk.y);
+                zn.y = opaque(zn.y);
+#endif
+                const cpx e = pw_opq({0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y)});
+                const cpx d = pw_opq({zk.x - zn.x, zk.y + zn.y});   // Zk - conj(Zn)
+                const cpx o = pw_opq({0.5f * d.y, -0.5f * d.x});    // d / (2i)
                 const cpx w = {L.tw_cos[k % MEL_N_FFT], -L.tw_sin[k % MEL_N_FFT]};
-                const cpx x = cadd(e, cmul(w, o));
+                const cpx x = pw_opq(cadd(e, pw_opq(cmul(w, o))));
+#if MEL_OPQ_PW
+                p = opaque(x.x * x.x) + x.y * x.y;
+#else
                 p = x.x * x.x + x.y * x.y;
+#endif
             }
             L.pw[wave][k] = p;
         }
@@ -209,8 +250,13 @@ __global__ __launch_bounds__(256) void mel_frames_kernel(const float *__restrict
                 const float *fv = &L.vals[tab->voff[j]];
                 const int ng = tab->ngrp[j];
                 for (int g = 0; g < ng; ++g) {
+#if MEL_OPQ_PW
+                    const float part = opaque(pv[4 * g] * fv[4 * g]) + opaque(pv[4 * g + 1] * fv[4 * g + 1]) +
+                                       opaque(pv[4 * g + 2] * fv[4 * g + 2]) + opaque(pv[4 * g + 3] * fv[4 * g + 3]);
+#else
                     const float part = pv[4 * g] * fv[4 * g] + pv[4 * g + 1] * fv[4 * g + 1] +
                                        pv[4 * g + 2] * fv[4 * g + 2] + pv[4 * g + 3] * fv[4 * g + 3];
+#endif
                     sum += (double)part;
                 }
                 sum += (double)(L.pw[wave][MEL_N_FREQ - 1] * tab->last[j]);

@@ -307,7 +307,9 @@ VadIterator *build_vad(const char *silero_file, int device, float gate_db, float
 
 void initialize_vad(transcription_filter_data *gf, const char *silero_vad_model_file) {
     // vad-processing.cpp:456-478: VadIterator(model, 16 kHz, 32 ms windows, 0.5, 100 / 100 / 100 ms)
-    gf->vad.reset(build_vad(silero_vad_model_file, gf->gpu_device, -40.0f, 3.0f, 0.5f));
+    // Only ever called with no worker running (start_whisper_thread_with_path, before the thread exists): the worker uses
+    // gf->vad outside whisper_ctx_mutex, so the object must not be replaced under it.
+    gf->vad.reset(build_vad(silero_vad_model_file, gf->gpu_device, gf->vad_gate_db, gf->vad_gate_slope_db, gf->vad_threshold));
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -297,6 +297,59 @@ def test_batched_steps_across_streams_equal_solo_runs(pkg, model_file):
             e.close()
 
 
+def test_successive_calls_with_different_audio_on_hub_contexts_equal_solo_runs(pkg, model_file):
+    # The hub's encoder lane reads a context's mel on ITS stream: it has to wait for the mel kernels of THIS call on the
+    # context's own stream (engine.hip pcm_to_mel sets st_dirty; round 2 left the flag clear after a context's first call, so
+    # a later call's encoder could read the previous call's mel).  10 streams alternate between two very different clips
+    # each, 4 calls in a row, all at once; greedy + no_context, so every call depends on its own audio only and must equal
+    # the solo transcript of that clip.
+    import threading
+    path = model_file("tiny.en", ftype=1, n_audio_layer=2, n_text_layer=2, n_audio_state=512, n_audio_head=8,
+                      n_text_state=512, n_text_head=8)
+    n_streams, steps, calls = 10, 12, 4
+    clips = [[ggml_io.synth_pcm(700 + 2 * i, 29.0), 0.2 * ggml_io.synth_pcm(701 + 2 * i, 4.0 + 0.3 * i)] for i in range(n_streams)]
+    first = pkg.Engine(path, precision=pkg.PRECISION_BF16)
+    engs = [first] + [pkg.Engine(path, precision=pkg.PRECISION_BF16, share=first) for _ in range(n_streams - 1)]
+    try:
+        params = []
+        for e in engs:
+            e.set_force_decode_steps(steps)
+        def par(e, clip):
+            return e.default_params(pkg.SAMPLING_GREEDY, temperature_inc=0.0, duration_ms=int(len(clip) * 1000 // 16000), language="en")
+        solo = []
+        for i, e in enumerate(engs):
+            row = []
+            for k in range(2):
+                assert e.full(par(e, clips[i][k]), clips[i][k]) == 0
+                row.append(e.segments())
+            assert row[0] != row[1]                       # the two clips of a stream do lead to different transcripts
+            solo.append(row)
+        out, errs = [[] for _ in range(n_streams)], []
+        gate = threading.Barrier(n_streams)
+
+        def work(i):
+            try:
+                gate.wait()
+                for k in range(calls):
+                    c = clips[i][k % 2]
+                    assert engs[i].full(par(engs[i], c), c) == 0
+                    out[i].append(engs[i].segments())
+            except Exception as ex:  # noqa: BLE001
+                errs.append(repr(ex))
+
+        th = [threading.Thread(target=work, args=(i,)) for i in range(n_streams)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, errs
+        for i in range(n_streams):
+            assert out[i] == [solo[i][k % 2] for k in range(calls)], f"stream {i}"
+    finally:
+        for e in engs[1:] + engs[:1]:
+            e.close()
+
+
 def test_mel_is_bit_exact_while_other_contexts_encode(pkg, model_file):
     # Regression: built with hipcc's SLP vectoriser (packed-f32 VALU), mel_frames_kernel returned a few wrong values per call
     # whenever kernels of OTHER contexts shared its compute units (alone it was bit-exact) — 150 of 240 calls differed.

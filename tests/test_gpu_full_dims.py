@@ -2,6 +2,7 @@
 
   BASELINE configs[2]  Whisper large-v3 dims (d=1280, 32+32 layers, 128 mel bins, vocab 51866), bf16, 5 rows per step
   BASELINE configs[3]  large-v3-turbo dims (4 decoder layers), bf16, 64 concurrent contexts on one upload of the weights
+  BASELINE configs[4]  large-v3 dims, e4m3 decoder weights, Silero-VAD-gated 3 s chunks with partials through whisper_loop
 
 Seeded synthetic weights in the GGML container (tools/synth_large; no checkpoints exist offline).  The bf16 engine cannot be
 token-exact against the fp32 oracle, so the comparison is teacher-forced: the ORACLE's token histories are fed to both
@@ -201,3 +202,96 @@ def test_turbo_dims_fp8_weights_teacher_forced_and_bit_equal_to_bf16_on_the_same
     worst = max(float(np.abs(a - b).max() / (b.max() - b.min())) for a, b in zip(q8, q16))
     print(f"e4m3 weights vs bf16 weights of an unrounded file: worst |d logits| / spread = {worst:.4f}")
     assert worst < 0.25
+
+
+def test_large_v3_dims_fp8_weights_teacher_forced(pkg, big_model):
+    """BASELINE configs[4], the model half at its own size: 32 decoder layers of e4m3 projections + the e4m3 logits matrix
+    against the fp32 oracle on the same (pre-rounded) weights, tolerances of the bf16 tests unchanged."""
+    _teacher_forced(pkg, big_model("large-v3", fp8_decoder=True), n_rows=5, steps=8, precision=pkg.PRECISION_FP8)
+
+
+@pytest.mark.parametrize("mode", ["active", "hybrid"])
+def test_config4_streaming_partials_large_v3_fp8_through_whisper_loop(pkg, big_model, tmp_path, mode):
+    """BASELINE configs[4] as ONE thing: large-v3 dims, e4m3 decoder weights, the Silero network on the GPU gating 3 s
+    segments with partials every 1100 ms, everything through the worker thread (whisper_loop ->
+    vad_based_segmentation -> run_inference_and_callbacks -> run_whisper_inference -> whisper_full;
+    /root/reference/src/whisper-utils/whisper-processing.cpp:326-431, vad-processing.cpp:202-367).
+      * the inference requests (PCM bytes, timestamps, VAD state) are those of the segmentation restatement driven by the
+        restated network;
+      * per request the fp8 filter returns what a bf16 filter returns on the same file: result enum, text, kept tokens with
+        their probabilities and the full whisper_full token sequence, equal to the bit (e4m3 -> bf16 is exact and the row
+        scales are powers of two; the model arithmetic itself is pinned by the teacher-forced test above).
+    12 forced tokens per call, beam 5 (the plugin's default strategy), temperature fallback off.  VAD mode ACTIVE cuts at the
+    network's speech ends (segment_duration is not read in that mode, vad-processing.cpp:202-367); HYBRID adds the 3 s cap
+    of segment_duration (vad-processing.cpp:369-454)."""
+    import time
+
+    from oracle import segmentation_oracle as sg
+    from oracle import silero_vad_oracle as so
+    from test_segmentation_cpu import speechlike
+
+    path = big_model("large-v3", fp8_decoder=True)
+    w = so.synth_weights(11)
+    vad_path = str(tmp_path / "silero_synth.onnx")
+    so.write_onnx(vad_path, w)
+    x = speechlike(7, 20.0)
+    vad_mode = sg.VAD_MODE_ACTIVE if mode == "active" else sg.VAD_MODE_HYBRID
+
+    def wait(cond, timeout_s):
+        t0 = time.time()
+        while time.time() - t0 < timeout_s:
+            if cond():
+                return True
+            time.sleep(0.005)
+        return False
+
+    def run(precision):
+        import ctypes
+        ctypes.CDLL(None).srand(1234)   # requests under 1 s are centred in rand() noise (whisper-processing.cpp:162-180): same stream for both runs
+        f = pkg.Filter(precision=precision)
+        requests, results = [], []
+
+        def on_text(d):
+            d["all_tokens"] = f.engine().token_ids()   # on the worker thread, behind its whisper_full: nobody else uses the context
+            results.append(d)
+
+        f.set_callbacks(on_text=on_text, on_request=lambda pcm, t0, t1, vs: requests.append((pcm, t0, t1, vs)))
+        try:
+            assert f.set_silero_model(vad_path) == 0
+            f.setup_audio(16000, 1)
+            f.L.lv_filter_set_vad_mode(f.f, vad_mode)
+            f.L.lv_filter_set_partial(f.f, 1, 1100)
+            f.L.lv_filter_set_segment_duration(f.f, 3000)
+            f.L.lv_filter_set_thresholds(f.f, 0.0, 1e6)
+            f.params.temperature_inc = 0.0
+            assert f.start(path) == 0 and f.L.lv_filter_vad_is_silero(f.f) == 1
+            f.engine().set_force_decode_steps(12)
+            orc = sg.SegmenterOracle(vad_mode=vad_mode, partial_transcription=True, partial_latency=1100,
+                                     segment_duration=3000, vad=sg.VadIteratorOracle(prob_source=so.SileroOracle(w)))
+            for i in range(0, len(x), 4000):   # lock-step with the worker, as the offline harness feeds (one pass per packet)
+                ts = 1_000_000_000 + i * 1_000_000_000 // 16000
+                assert f.push_packet([x[i:i + 4000]], ts) == 0
+                orc.push_packet(x[i:i + 4000], ts)
+                orc.step()
+                assert wait(lambda: f.L.lv_filter_input_bytes(f.f) == 0, 30.0)
+                assert wait(lambda: len(requests) >= len(orc.requests) and len(results) >= len(orc.requests), 60.0)
+            f.stop()
+            assert len(requests) == len(orc.requests) == len(results)
+            for (pcm, t0, t1, vs), r in zip(requests, orc.requests):
+                assert (t0, t1, vs) == (r.t0, r.t1, r.vad_state) and np.array_equal(pcm, r.pcm)
+            return requests, results
+        finally:
+            f.close()
+
+    req8, res8 = run(pkg.PRECISION_FP8)
+    req16, res16 = run(pkg.PRECISION_BF16)
+    n_partial = sum(vs == sg.VAD_STATE_PARTIAL for _, _, _, vs in req8)
+    print(f"configs[4]: {len(req8)} inference requests ({n_partial} partial), "
+          f"{sum(len(r['all_tokens']) for r in res8)} tokens; mean chunk {np.mean([len(p) for p, _, _, _ in req8]) / 16000:.2f} s")
+    assert len(req8) >= 6 and (mode == "hybrid" or 0 < n_partial < len(req8))
+    assert all(len(p) <= 16000 * 11 for p, _, _, _ in req8)                  # MAX_MS_WORK_BUFFER
+    # (random weights: a timestamp token may close a call's segment before the forced length, and a chunk under 1 s is padded)
+    assert all(len(r["all_tokens"]) >= 1 for r in res8) and sum(len(r["all_tokens"]) >= 4 for r in res8) >= len(res8) // 2
+    assert len({tuple(r["all_tokens"]) for r in res8}) > 1                   # ... and the chunks lead to different transcripts
+    for k, (a, b) in enumerate(zip(res8, res16)):
+        assert a == b, f"request {k} ({len(req8[k][0])} samples, VAD state {req8[k][3]})"
