@@ -675,8 +675,8 @@ void Hub::run(Lane &ln, const std::vector<StepRequest *> &batch) {
         int lr = 0;
         for (StepRequest *q : batch) {
             if (q->keep_logits && q->n_logit_rows > 0)
-                MW_HIP(hipMemcpyAsync(q->c->d_logits, d_logits + (size_t)lr * nv, (size_t)q->n_logit_rows * nv * sizeof(float),
-                                      hipMemcpyDeviceToDevice, st));
+                MW_HIP(hipMemcpyAsync(q->c->d_logits + (size_t)q->logits_dst_row * nv, d_logits + (size_t)lr * nv,
+                                      (size_t)q->n_logit_rows * nv * sizeof(float), hipMemcpyDeviceToDevice, st));
             lr += q->n_logit_rows;
         }
     }
@@ -901,26 +901,51 @@ void decode(Context &c, const int *tokens, const int *pos, const int *slot, int 
         MW_CHECK(slot[i] >= 0 && slot[i] < KV_SLOTS, "decode: bad sequence slot");
     }
     for (int i = 0; i < n_logit_rows; ++i) MW_CHECK(logit_rows[i] >= 0 && logit_rows[i] < n, "decode: bad logits row");
-    if (c.tile_step && c.use_hub && c.model.hub && n <= STEP_MAX_ROWS && n_logit_rows <= STEP_MAX_ROWS &&
-        (!c.ps_armed || c.ps_n <= STEP_MAX_ROWS)) {
+    if (c.tile_step && c.use_hub && c.model.hub && (!c.ps_armed || c.ps_n <= STEP_MAX_ROWS)) {
         // batched path: the step runs on the hub of the contexts that share these weights, together with whatever other
-        // contexts have queued meanwhile (one pass over the weights for all their rows)
-        const double t0h = now_ms();
-        StepRequest r;
-        r.c = &c;
-        r.tokens = tokens; r.pos = pos; r.slot = slot; r.n = n;
-        r.logit_rows = logit_rows; r.n_logit_rows = n_logit_rows;
-        r.sample = c.ps_armed && c.fuse_sample && n_logit_rows > 0 && c.prof_tag < 0;
-        r.keep_logits = !r.sample && n_logit_rows > 0;
-        r.solo = c.prof_tag >= 0 || c.dup_tag >= 0 || !c.use_graphs;
-        if (r.sample) r.rules_key = std::string((const char *)&c.ps_lp, sizeof(c.ps_lp)) + "|" + c.suppress_key;
-        if (c.st_dirty) MW_HIP(hipEventRecord(c.ev_ready, c.st));
-        c.model.hub->submit(r);
-        c.ps_fused = r.sample;  // the results are in h_row_res already
-        c.n_logit_rows = n_logit_rows;
-        c.tm.n_decode++;
-        c.tm.decode_ms += now_ms() - t0h;
-        return;
+        // contexts have queued meanwhile (one pass over the weights for all their rows).  A call of more than STEP_MAX_ROWS
+        // rows (a long prompt: initial_prompt / prompt_past, whisper-processing.cpp:191-199) goes through in chunks of
+        // STEP_MAX_ROWS consecutive rows, one step each — one pass over the weights per 16 tokens on the matrix-core tile
+        // kernels; a chunk's rows see the K / V of the chunks before it through the cache (a kernel boundary apart).
+        const bool want_sample = c.ps_armed && c.fuse_sample && n_logit_rows > 0 && c.prof_tag < 0;
+        const int n_chunks = ceil_div(n, STEP_MAX_ROWS), last0 = (n_chunks - 1) * STEP_MAX_ROWS;
+        bool chunkable = n_chunks == 1 || (c.prof_tag < 0 && c.dup_tag < 0 && c.use_graphs);
+        if (n_chunks > 1) {
+            // logits rows in call order (the copies below land them in that order); a fused sampler wants them all in the
+            // last chunk (its rows index the step's logits rows)
+            for (int i = 1; i < n_logit_rows; ++i) chunkable = chunkable && logit_rows[i] > logit_rows[i - 1];
+            if (want_sample)
+                for (int i = 0; i < n_logit_rows; ++i) chunkable = chunkable && logit_rows[i] >= last0;
+        }
+        if (chunkable) {
+            const double t0h = now_ms();
+            int lr_done = 0;
+            bool fused = false;
+            for (int ch = 0; ch < n_chunks; ++ch) {
+                const int r0 = ch * STEP_MAX_ROWS, nr = std::min(STEP_MAX_ROWS, n - r0);
+                int lrows[STEP_MAX_ROWS], nl = 0;
+                for (int i = 0; i < n_logit_rows; ++i)
+                    if (logit_rows[i] >= r0 && logit_rows[i] < r0 + nr) lrows[nl++] = logit_rows[i] - r0;
+                StepRequest r;
+                r.c = &c;
+                r.tokens = tokens + r0; r.pos = pos + r0; r.slot = slot + r0; r.n = nr;
+                r.logit_rows = lrows; r.n_logit_rows = nl;
+                r.sample = want_sample && nl > 0 && ch == n_chunks - 1;
+                r.keep_logits = !r.sample && nl > 0;
+                r.logits_dst_row = lr_done;
+                r.solo = c.prof_tag >= 0 || c.dup_tag >= 0 || !c.use_graphs;
+                if (r.sample) r.rules_key = std::string((const char *)&c.ps_lp, sizeof(c.ps_lp)) + "|" + c.suppress_key;
+                if (c.st_dirty) MW_HIP(hipEventRecord(c.ev_ready, c.st));
+                c.model.hub->submit(r);
+                fused = fused || r.sample;
+                lr_done += nl;
+                c.tm.n_decode++;
+            }
+            c.ps_fused = fused;  // the results are in h_row_res already
+            c.n_logit_rows = n_logit_rows;
+            c.tm.decode_ms += now_ms() - t0h;
+            return;
+        }
     }
     hipStream_t st = c.st;
     const bool tile = c.tile_step && n <= 5;  // bf16 rows between attention / MLP kernels and the residual projections

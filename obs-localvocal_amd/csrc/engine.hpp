@@ -57,6 +57,7 @@ struct StepRequest {
     int n_logit_rows = 0;
     bool sample = false;       // the context's prepared rules + sampler rows ride in the step (results -> c->h_row_res)
     bool keep_logits = false;  // copy the request's logits rows into c->d_logits (stage calls, language detection, unfused sampler)
+    int logits_dst_row = 0;    // ... from this row of c->d_logits on (a long call travels as several requests)
     bool solo = false;         // measurement hooks armed on the context: never batched with other requests
     std::string rules_key;     // requests share a step only when their rules + sampler parameters are identical
     std::condition_variable cv;  // the owner sleeps here until its step is done or it is its turn to lead

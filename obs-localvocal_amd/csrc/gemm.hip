@@ -585,7 +585,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GS == 1 ? 4
 // k-loop): the workgroups are PERSISTENT — min(tiles, 256) of them, each walking tiles of an XCD-contiguous range — and the
 // first k-step of a workgroup's next tile is issued before the epilogue of the current one, so the stores of tile i and the
 // cold loads of tile i + 1 overlap.  No batch dimension; needs K % 64 == 0, N % 256 == 0; no transposed store.
-template <typename TOUT>
+// V: development variants measured with tools/microbench/mb_gemm (bit 0: next step's W loads issued with its A loads at the
+// top of the step; bit 1: s_setprio around the MFMA blocks; bits 2-4 are diagnostics that compute WRONG results: no epilogue /
+// no MFMAs / no loads after a tile's first step).  The library instantiates V = 0 only.
+template <typename TOUT, int V = 0>
 __global__ __launch_bounds__(512) void gemm_bf16_256_kernel(GemmArgs a) {
     constexpr int BK = 64, RB = 128, HALF = 128 * RB, STAGE = 4 * HALF;
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
@@ -662,9 +665,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_256_kernel(GemmArgs a) {
             const int wcol = (wc & 1) * 64;
             const bool last = kt + 1 == nk;
             if (last && have_next) point(m1, n1);  // the loads below then fetch step 0 of the next tile
-            const bool more = !last || have_next;
+            const bool more = (V & 16) ? false : (!last || have_next);
             const int nkt = last ? 0 : kt + 1;
             if (more) issue_a(nkt, par ^ 1);
+            if ((V & 1) && more) issue_w(nkt, par ^ 1);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 bf16x8 bfr[4];
@@ -675,14 +679,23 @@ __global__ __launch_bounds__(512) void gemm_bf16_256_kernel(GemmArgs a) {
                     bf16x8 af[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8 *>(la + swz8(hh * 64 + i * 16 + fr, 4 * ks + fq));
+                    if (V & 2) __builtin_amdgcn_s_setprio(1);
+                    if (V & 8) {  // diagnostic: fragments consumed without the matrix cores
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc[hh * 4 + i][j][0] += __builtin_bit_cast(f32x4, bfr[j])[0] + __builtin_bit_cast(f32x4, af[i])[1];
+                    } else {
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
                             acc[hh * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                                 __builtin_bit_cast(bf16x8b, bfr[j]), __builtin_bit_cast(bf16x8b, af[i]), acc[hh * 4 + i][j], 0, 0, 0);
+                    }
+                    if (V & 2) __builtin_amdgcn_s_setprio(0);
                 }
-                if (ks == 0 && more) issue_w(nkt, par ^ 1);
+                if (!(V & 1) && ks == 0 && more) issue_w(nkt, par ^ 1);
             }
             par ^= 1;
         }
@@ -693,7 +706,18 @@ __global__ __launch_bounds__(512) void gemm_bf16_256_kernel(GemmArgs a) {
         // one wave execute in order, so no further barrier), and leaves as whole lines: 16 lanes cover one row's 64 columns
         // (256 bytes of fp32 / 128 of bf16), the residual is read the same way, the lane's four bias values once.
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave has read the last k-step
-        {
+        if ((V & 16) && have_next) {  // (diagnostic: the next tile's first step, which the k-loop did not issue)
+            issue_a(0, par);
+            issue_w(0, par);
+        }
+        if (V & 4) {  // diagnostic: no epilogue (one store per lane keeps the accumulators alive)
+            float t = 0.0f;
+#pragma unroll
+            for (int i8 = 0; i8 < 8; ++i8)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t += acc[i8][j][0] + acc[i8][j][1] + acc[i8][j][2] + acc[i8][j][3];
+            if (t == 1234.5f) C[m0 * (long)a.ldc + n0 + lane] = (TOUT)t;
+        } else {
             constexpr int SROW = 64 + 4;  // floats per staged row (padding: conflict-free 16-byte column accesses)
             float *stg = reinterpret_cast<float *>(lds + (par ^ 1) * STAGE + wave * (16 * SROW * 4 + 256));
             const int erow = lane >> 4, ecol = 4 * (lane & 15);  // read side: 4 rows x 64 columns per instruction
@@ -794,7 +818,7 @@ void launch_gemm(const GemmArgs &args, DType in, DType out, hipStream_t st) {
     // Q|K and fc1 from M = 6000 on
     const long tiles256 = (long)(a.N / 256) * ceil_div(a.M, 256);
     const bool big = in == DType::BF16 && !a.trans_c && a.K % 64 == 0 && a.K >= 256 && a.N % 256 == 0 && a.nz0 * a.nz1 == 1 &&
-                     a.epi_vec && (a.glds == 8 || (a.glds == 0 && tiles256 >= 200));
+                     a.epi_vec && (a.glds == 8 || a.glds >= 100 || (a.glds == 0 && tiles256 >= 200));
     const int bm = big ? 256 : bm64 ? 64 : 128, bn = big ? 256 : BN;
     dim3 grid(ceil_div(a.N, bn), ceil_div(a.M, bm), a.nz0 * a.nz1);
     MW_CHECK(grid.y <= 65535, "gemm: M too large for grid.y");
@@ -835,8 +859,17 @@ void launch_gemm(const GemmArgs &args, DType in, DType out, hipStream_t st) {
     if (big) {
         // persistent: one workgroup per CU at most, a multiple of 8 so that every XCD's range is walked in step
         const dim3 pgrid((unsigned)std::min<long>(ceil_div<long>((long)grid.x * grid.y, 8) * 8, 256));
+#ifdef MW_GEMM_VARIANTS
+#define V256(v) case 100 + v: if (out == DType::F32) hipLaunchKernelGGL((gemm_bf16_256_kernel<float, v>), pgrid, dim3(512), 0, st, a); \
+                             else hipLaunchKernelGGL((gemm_bf16_256_kernel<bf16_t, v>), pgrid, dim3(512), 0, st, a); break;
+        switch (a.glds) { V256(1) V256(2) V256(3) V256(4) V256(8) V256(12) V256(16) V256(20) V256(28) default:
+#endif
         if (out == DType::F32) hipLaunchKernelGGL((gemm_bf16_256_kernel<float>), pgrid, dim3(512), 0, st, a);
         else hipLaunchKernelGGL((gemm_bf16_256_kernel<bf16_t>), pgrid, dim3(512), 0, st, a);
+#ifdef MW_GEMM_VARIANTS
+        }
+#undef V256
+#endif
     } else if (many && out == DType::F32) {
         if (a.trans_c) hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, 128, true, 1>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, 128, false, 1>), grid, dim3(256), 0, st, a);

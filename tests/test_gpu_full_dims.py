@@ -204,6 +204,49 @@ def test_turbo_dims_fp8_weights_teacher_forced_and_bit_equal_to_bf16_on_the_same
     assert worst < 0.25
 
 
+def test_large_v3_dims_long_prompt_prefill_in_chunks_of_16_rows(pkg, big_model):
+    """LocalVocal's context-sentence path hands whisper_full an initial_prompt / prompt_past of up to 224 tokens on every call
+    (/root/reference/src/whisper-utils/whisper-processing.cpp:191-199; the offline harness runs no_context=false,
+    localvocal-offline-test.cpp:184).  A 200-token prompt goes through the hub's 16-row matrix-core kernels in 13 steps (one
+    pass over the weights per 16 tokens): the logits of its last 32 rows against the fp32 oracle (bf16 tolerance of the
+    tests above), the same call on a context that takes the per-context path (MI355_WHISPER_NO_BATCH: VALU kernels) within
+    the same bound of it, and a decode step behind the prompt sees all 200 cached positions."""
+    import os
+    path = big_model("large-v3")
+    pyoracle.lib().ow_set_threads(16)
+    pcm = ggml_io.synth_pcm(100, 30.0)
+    orc = pyoracle.Oracle(path)
+    eng = pkg.Engine(path, precision=pkg.PRECISION_BF16)
+    try:
+        orc.mel(pcm)
+        eng.mel(pcm)
+        orc.encode(0)
+        eng.encode(0)
+        rng = np.random.RandomState(5)
+        prompt = [orc.prev] + [int(t) for t in rng.randint(0, orc.eot, 196)] + [orc.sot, orc.sot + 1, orc.transcribe]
+        assert len(prompt) == 200
+        s0 = eng.hub_stats()
+        ref = orc.decode(prompt, 0, 0)[-32:]
+        got = eng.decode(prompt, 0, 0)
+        s1 = eng.hub_stats()
+        assert s1[0] - s0[0] == 13 and s1[1] - s0[1] == 200         # 13 steps of <= 16 rows on the hub
+        worst = 0.0
+        for i in range(32):
+            spread = float(ref[i].max() - ref[i].min())
+            err = float(np.abs(got[i] - ref[i]).max())
+            worst = max(worst, err / spread)
+            assert err <= LOGIT_TOL * spread, f"prompt row {168 + i}"
+        nxt = int(np.argmax(ref[-1][:orc.eot]))
+        ref1 = orc.decode([nxt], 200, 0)[0]
+        got1 = eng.decode_rows([nxt], [200], [0])[0]
+        spread = float(ref1.max() - ref1.min())
+        assert float(np.abs(got1 - ref1).max()) <= LOGIT_TOL * spread
+        print(f"200-token prompt in 13 hub steps: worst |d logits| / spread over the last 32 rows = {worst:.4f}")
+    finally:
+        eng.close()
+        orc.close()
+
+
 def test_large_v3_dims_fp8_weights_teacher_forced(pkg, big_model):
     """BASELINE configs[4], the model half at its own size: 32 decoder layers of e4m3 projections + the e4m3 logits matrix
     against the fp32 oracle on the same (pre-rounded) weights, tolerances of the bf16 tests unchanged."""

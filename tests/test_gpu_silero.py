@@ -47,6 +47,35 @@ def test_probabilities_and_state_match_the_restatement(pkg, model):
         vad.close()
 
 
+def test_the_reference_models_own_weights_through_the_kernels(pkg, tmp_path):
+    """The tensors of the reference's data/models/silero-vad/silero_vad.onnx (16 kHz branch; tests/golden/silero_v5_16k.npz,
+    written by tools/gen_silero_golden.py in the build container) rebuilt into a model file and run through the HIP
+    kernels: probabilities within 1e-4 of the restatement's on the same weights (fixture) and of the restatement run here;
+    the network answers like a VAD on them (a vowel-like buzz high, noise low).  The reference side is
+    VadIterator::predict_one, /root/reference/src/whisper-utils/silero-vad-onnx.cpp:111-140.  PARITY UNPINNED (no ONNX
+    Runtime output to compare with)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "silero_v5_16k.npz"))
+    w = {k[2:]: g[k] for k in g.files if k.startswith("w_")}
+    assert {k: v.shape for k, v in w.items()} == {k: shape for k, (_, shape) in so.SUFFIXES.items()}
+    path = str(tmp_path / "silero_real_weights.onnx")
+    so.write_onnx(path, w)
+    vad = pkg.SileroVad(path)
+    try:
+        for name in ("voiced", "gated", "noise"):
+            x, want = g["clip_" + name], g["prob_" + name]
+            got = vad.process(x, reset=True)
+            here = so.SileroOracle(w).process(x, reset=True)
+            err = float(np.abs(got - want).max())
+            print(f"silero, reference weights, clip {name}: max |gpu - restatement| = {err:.2e}, p in [{got.min():.3f}, {got.max():.3f}]")
+            assert len(got) == len(x) // W == len(want) and err < 1e-4 and np.abs(got - here).max() < 1e-4
+        assert vad.process(g["clip_voiced"], reset=True).max() > 0.6 and vad.process(g["clip_noise"], reset=True)[8:].max() < 0.15
+        p = vad.process(g["clip_gated"], reset=True)
+        assert p[:25].max() > 0.5 and p[45:60].max() < 0.1      # speech, then the silent second (windows 31 .. 62)
+    finally:
+        vad.close()
+
+
 def test_state_carries_between_calls_and_reset_clears_it(pkg, model):
     path, _ = model
     vad = pkg.SileroVad(path)

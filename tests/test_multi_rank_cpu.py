@@ -78,3 +78,22 @@ def test_bench_launches_its_own_ranks():
     assert rec["n_gpus"] == 2 and rec["dry_run"] is True
     assert rec["streams_per_rank"] == [4, 3]                 # stream i -> rank i mod 2
     assert rec["elapsed_max_s"] >= 0.02                      # rank 1 is the slow one (MAX over ranks)
+
+
+def test_dry_run_line_of_the_default_workload_carries_the_streams_object():
+    # `bench.py --gpus N` as the driver runs it (default workload = the weak-scaling headline) also measures BASELINE
+    # configs[3] — 64 turbo streams sharded i mod N, strong scaling — on the same ranks and attaches it as `streams`
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["scaling"] == "weak" and rec["streams_per_rank"] == [1, 1]
+    st = rec["streams"]
+    assert st["scaling"] == "strong" and st["n_gpus"] == 2 and st["streams_per_rank"] == [32, 32]

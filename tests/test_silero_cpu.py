@@ -106,3 +106,14 @@ def test_filter_without_the_model_file_keeps_the_energy_gate(pkg, tmp_path):
         assert len(f.vad_probabilities()) == len(x) // 512
     finally:
         f.close()
+
+
+@pytest.mark.skipif(not os.path.exists(REAL), reason="the reference's silero_vad.onnx is not on this machine")
+def test_golden_fixture_holds_the_reference_files_tensors():
+    # tests/golden/silero_v5_16k.npz (tools/gen_silero_golden.py) is what the GPU test sends through the kernels
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "silero_v5_16k.npz"))
+    w = so.load_weights(REAL)
+    assert sorted(k[2:] for k in g.files if k.startswith("w_")) == sorted(w)
+    assert all(np.array_equal(g["w_" + k], np.asarray(v, dtype=np.float32)) for k, v in w.items())
+    for name in ("voiced", "gated", "noise"):
+        assert np.abs(so.SileroOracle(w).process(g["clip_" + name]) - g["prob_" + name]).max() < 1e-6

@@ -1,5 +1,7 @@
 // Development microbenchmark: the encoder's GEMM shapes through launch_gemm at M = windows x 1500 rows.
-//   make -C tools/microbench mb_gemm && ./mb_gemm [variant]
+//   make -C tools/microbench mb_gemm && ./mb_gemm [variant [windows ...]]
+// variant: GemmArgs::glds (0 = launch_gemm's own choice, 8 = the 256 x 256 kernel, 100 + V = its development variant V)
+#define MW_GEMM_VARIANTS 1
 #include "../../obs-localvocal_amd/csrc/gemm.hip"
 
 #include <cstdio>
@@ -16,8 +18,11 @@ int main(int argc, char **argv) {
                             {"fc1", 4 * d, d, false, true, false}, {"fc2", d, 4 * d, true, false, true},
                             {"fc1n", 4 * d, d, false, false, false}, {"outn", d, d, true, false, false},
                             {"outb", d, d, false, false, false}, {"fc2b", d, 4 * d, false, false, false}};
-    const int Ws[] = {1, 4, 8};
-    const size_t maxM = 8 * 1500;
+    std::vector<int> Ws;
+    for (int i = 2; i < argc; ++i) Ws.push_back(atoi(argv[i]));
+    if (Ws.empty()) Ws = {1, 4, 8};
+    size_t maxM = 1500;
+    for (int w : Ws) maxM = std::max<size_t>(maxM, (size_t)w * 1500);
     void *A, *Wt, *C; float *bias;
     MW_HIP(hipMalloc(&A, maxM * 4 * d * 2)); MW_HIP(hipMalloc(&Wt, (size_t)4 * d * d * 2)); MW_HIP(hipMalloc(&C, maxM * 4 * d * 4));
     MW_HIP(hipMalloc((void **)&bias, 4 * d * 4));
@@ -29,7 +34,7 @@ int main(int argc, char **argv) {
     hipStream_t st; MW_HIP(hipStreamCreate(&st));
     hipEvent_t e0, e1; MW_HIP(hipEventCreate(&e0)); MW_HIP(hipEventCreate(&e1));
     // correctness of the variant against variant 0 (same k order: bit-identical), on the W = 1 shapes without residual aliasing
-    if (variant != 0) {
+    if (variant != 0 && !(variant >= 100 && ((variant - 100) & 28))) {  // (diagnostic variants compute wrong results on purpose)
         void *C0;
         MW_HIP(hipMalloc(&C0, (size_t)1500 * 4 * d * 4));
         for (const Shape &s : shapes) {
