@@ -15,6 +15,8 @@
 // LDS tile stored k-major.
 #include "kernels.hpp"
 
+#include <type_traits>
+
 #include <hip/hip_bf16.h>
 
 #include <cmath>
@@ -44,7 +46,9 @@ __device__ __forceinline__ float gelu_f(float x) {
 __device__ __forceinline__ float gelu_fast(float x) {
     const float c2 = 2.0f * 0.79788456080286535587989211986876f, a = 0.044715f;
     const float u2 = c2 * x * fmaf(a * x, x, 1.0f);
-    return __fdividef(x, 1.0f + __expf(-u2));
+    // x * rcp(1 + e): __fdividef is a full IEEE division on this compiler (two v_div_scale, v_rcp, four fma, v_div_fmas,
+    // v_div_fixup: 20 instructions per element instead of 9, found in the ISA of the 256 x 256 kernel's epilogue)
+    return x * __builtin_amdgcn_rcpf(1.0f + __expf(-u2));
 }
 
 __device__ __forceinline__ void store_out(float *p, float v) { *p = v; }
@@ -262,6 +266,11 @@ __device__ __forceinline__ void gemm_bf16_epilogue(const GemmArgs &a, f32x4 (&ac
         // vector form (launch_gemm checked N % 4 == 0 and the 16-byte alignment of bias, residual and output rows): every
         // load is unconditional — out-of-range lanes read a clamped address — because a branch around a load ends in a wait
         // for ALL loads in flight at its join, the next tile's operand loads included; only the store is predicated
+        // Tiles that lie wholly inside the matrix (all but the last row of tiles at M = 1500) take the FULL form: no store
+        // predicate at all.  With the predicate the compiler sinks the conversions under it and opens every predicated block
+        // with a wait for whatever is in flight (found in the 256 x 256 kernel's listing: one store acknowledgement per block).
+        auto run = [&](auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
         float bj[WJ][4];
 #pragma unroll
         for (int j = 0; j < WJ; ++j) {
@@ -273,7 +282,7 @@ __device__ __forceinline__ void gemm_bf16_epilogue(const GemmArgs &a, f32x4 (&ac
         for (int i = 0; i < 4; ++i) {
             // one row tile at a time: left alone the scheduler hoists every residual load of the epilogue to its top
             __builtin_amdgcn_sched_barrier(0);
-            const int mb = m0 + wr * 64 + i * 16 + (lane & 15), mc = min(mb, M - 1);
+            const int mb = m0 + wr * 64 + i * 16 + (lane & 15), mc = FULL ? mb : min(mb, M - 1);
             float4 rv[WJ];
 #pragma unroll
             for (int j = 0; j < WJ; ++j) {
@@ -293,8 +302,8 @@ __device__ __forceinline__ void gemm_bf16_epilogue(const GemmArgs &a, f32x4 (&ac
                     if (R) x += rr[r];
                     v[r] = x;
                 }
-                TOUT *dst = C + (long)mc * a.ldc + min(nb, N - 4);
-                if (mb < M && nb < N) {
+                TOUT *dst = C + (long)mc * a.ldc + (FULL ? nb : min(nb, N - 4));
+                if (FULL || (mb < M && nb < N)) {
                     if constexpr (sizeof(TOUT) == 4) {
                         *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
                     } else {
@@ -308,6 +317,9 @@ __device__ __forceinline__ void gemm_bf16_epilogue(const GemmArgs &a, f32x4 (&ac
                 }
             }
         }
+        };
+        if (m0 + BM <= M && n0 + BN <= N) run(std::true_type{});
+        else run(std::false_type{});
         return;
     }
 #pragma unroll
@@ -585,10 +597,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GS == 1 ? 4
 // k-loop): the workgroups are PERSISTENT — min(tiles, 256) of them, each walking tiles of an XCD-contiguous range — and the
 // first k-step of a workgroup's next tile is issued before the epilogue of the current one, so the stores of tile i and the
 // cold loads of tile i + 1 overlap.  No batch dimension; needs K % 64 == 0, N % 256 == 0; no transposed store.
-// V: development variants measured with tools/microbench/mb_gemm (bit 0: next step's W loads issued with its A loads at the
-// top of the step; bit 1: s_setprio around the MFMA blocks; bits 2-4 are diagnostics that compute WRONG results: no epilogue /
-// no MFMAs / no loads after a tile's first step).  The library instantiates V = 0 only.
-template <typename TOUT, int V = 0>
+// The epilogue's shape is a compile-time choice (HAS_R: fp32 residual added, GELU: tanh-GELU): as run-time branches around
+// its loads and stores every slice ended in a wait at the branch's join.
+template <typename TOUT, bool HAS_R, bool GELU>
 __global__ __launch_bounds__(512) void gemm_bf16_256_kernel(GemmArgs a) {
     constexpr int BK = 64, RB = 128, HALF = 128 * RB, STAGE = 4 * HALF;
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
@@ -665,10 +676,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_256_kernel(GemmArgs a) {
             const int wcol = (wc & 1) * 64;
             const bool last = kt + 1 == nk;
             if (last && have_next) point(m1, n1);  // the loads below then fetch step 0 of the next tile
-            const bool more = (V & 16) ? false : (!last || have_next);
+            const bool more = !last || have_next;
             const int nkt = last ? 0 : kt + 1;
             if (more) issue_a(nkt, par ^ 1);
-            if ((V & 1) && more) issue_w(nkt, par ^ 1);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 bf16x8 bfr[4];
@@ -679,23 +689,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_256_kernel(GemmArgs a) {
                     bf16x8 af[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8 *>(la + swz8(hh * 64 + i * 16 + fr, 4 * ks + fq));
-                    if (V & 2) __builtin_amdgcn_s_setprio(1);
-                    if (V & 8) {  // diagnostic: fragments consumed without the matrix cores
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) acc[hh * 4 + i][j][0] += __builtin_bit_cast(f32x4, bfr[j])[0] + __builtin_bit_cast(f32x4, af[i])[1];
-                    } else {
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
                             acc[hh * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                                 __builtin_bit_cast(bf16x8b, bfr[j]), __builtin_bit_cast(bf16x8b, af[i]), acc[hh * 4 + i][j], 0, 0, 0);
-                    }
-                    if (V & 2) __builtin_amdgcn_s_setprio(0);
                 }
-                if (!(V & 1) && ks == 0 && more) issue_w(nkt, par ^ 1);
+                if (ks == 0 && more) issue_w(nkt, par ^ 1);
             }
             par ^= 1;
         }
@@ -706,66 +707,98 @@ __global__ __launch_bounds__(512) void gemm_bf16_256_kernel(GemmArgs a) {
         // one wave execute in order, so no further barrier), and leaves as whole lines: 16 lanes cover one row's 64 columns
         // (256 bytes of fp32 / 128 of bf16), the residual is read the same way, the lane's four bias values once.
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave has read the last k-step
-        if ((V & 16) && have_next) {  // (diagnostic: the next tile's first step, which the k-loop did not issue)
-            issue_a(0, par);
-            issue_w(0, par);
-        }
-        if (V & 4) {  // diagnostic: no epilogue (one store per lane keeps the accumulators alive)
-            float t = 0.0f;
-#pragma unroll
-            for (int i8 = 0; i8 < 8; ++i8)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) t += acc[i8][j][0] + acc[i8][j][1] + acc[i8][j][2] + acc[i8][j][3];
-            if (t == 1234.5f) C[m0 * (long)a.ldc + n0 + lane] = (TOUT)t;
-        } else {
+        {
             constexpr int SROW = 64 + 4;  // floats per staged row (padding: conflict-free 16-byte column accesses)
             float *stg = reinterpret_cast<float *>(lds + (par ^ 1) * STAGE + wave * (16 * SROW * 4 + 256));
-            const int erow = lane >> 4, ecol = 4 * (lane & 15);  // read side: 4 rows x 64 columns per instruction
-            const int nb = n0 + wc * 64 + ecol;
-            const float4 b4 = *reinterpret_cast<const float4 *>(a.bias ? a.bias + nb : a.epi_zero);
+            const int ncol0 = n0 + wc * 64;
+            // A row predicate around the stores made the compiler sink each slice's work under it and open every one of the
+            // 16 predicated blocks with s_waitcnt vmcnt(0): every store waited for the acknowledgement of the one before
+            // (and the first for the next tile's DMA).  Only the last row of tiles can be partial (M = windows x 1500), so the
+            // choice is made once per tile, workgroup-uniform: FULL tiles run straight-line code without any predicate.
+            auto epilogue = [&](auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
+            if constexpr (sizeof(TOUT) == 4) {
+                // fp32 out (the residual stream): a lane takes 4 columns, 16 lanes one row's 64 columns (256 bytes), 4 rows per
+                // instruction; the residual is read the same way.  The row predicate stays on these stores ON PURPOSE: the
+                // compiler then waits for each store's acknowledgement before the next slice's loads, and that throttle is
+                // FASTER here — the straight-line form (residual rows prefetched a slice ahead, 32 stores in flight per wave)
+                // measured 109 vs 92 us (attention output) and 290 vs 273 us (fc2) at M = 24 000: all 256 CUs read and write
+                // the same fp32 stream at once, and interleaved bursts of both cost more than they hide.
+                const int erow = lane >> 4, ecol = 4 * (lane & 15), nb = ncol0 + ecol;
+                const float4 b4 = *reinterpret_cast<const float4 *>(a.bias ? a.bias + nb : a.epi_zero);
 #pragma unroll
-            for (int i8 = 0; i8 < 8; ++i8) {
+                for (int i8 = 0; i8 < 8; ++i8) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    f32x4 v = acc[i8][j];
-                    v *= a.alpha;
-                    *reinterpret_cast<f32x4 *>(stg + (lane & 15) * SROW + 16 * j + 4 * (lane >> 4)) = v;
-                }
-                const int mrow0 = m0 + wr * 128 + i8 * 16;
-                float4 rv[4];
-#pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const int m = min(mrow0 + erow + 4 * it, M - 1);
-                    rv[it] = a.R ? *reinterpret_cast<const float4 *>(a.R + (long)m * a.ldr + nb) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                }
-#pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const int mr = mrow0 + erow + 4 * it;
-                    const f32x4 t = *reinterpret_cast<const f32x4 *>(stg + (erow + 4 * it) * SROW + ecol);
-                    float x[4] = {t[0], t[1], t[2], t[3]};
-                    const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, rr[4] = {rv[it].x, rv[it].y, rv[it].z, rv[it].w};
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (a.bias) x[r] += bb[r];
-                        if (a.act == ACT_GELU) x[r] = gelu_fast(x[r]);
-                        if (a.R) x[r] += rr[r];
+                    for (int j = 0; j < 4; ++j) {
+                        f32x4 v = acc[i8][j];
+                        v *= a.alpha;
+                        *reinterpret_cast<f32x4 *>(stg + (lane & 15) * SROW + 16 * j + 4 * (lane >> 4)) = v;
                     }
-                    TOUT *dst = C + (long)min(mr, M - 1) * a.ldc + nb;
-                    if (mr < M) {
-                        if constexpr (sizeof(TOUT) == 4) {
-                            *reinterpret_cast<float4 *>(dst) = make_float4(x[0], x[1], x[2], x[3]);  // the residual stream: read again at once
-                        } else {
-                            __hip_bfloat16 h0 = __float2bfloat16(x[0]), h1 = __float2bfloat16(x[1]), h2 = __float2bfloat16(x[2]),
-                                           h3 = __float2bfloat16(x[3]);
-                            using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
-                            u32x2 pk;
-                            pk.x = (unsigned)*reinterpret_cast<bf16_t *>(&h0) | ((unsigned)*reinterpret_cast<bf16_t *>(&h1) << 16);
-                            pk.y = (unsigned)*reinterpret_cast<bf16_t *>(&h2) | ((unsigned)*reinterpret_cast<bf16_t *>(&h3) << 16);
-                            __builtin_nontemporal_store(pk, reinterpret_cast<u32x2 *>(dst));  // 60-120 MB read once by the next kernel
+                    const int mrow0 = m0 + wr * 128 + i8 * 16;
+                    float4 rv[4];
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int m = min(mrow0 + erow + 4 * it, M - 1);
+                        if constexpr (HAS_R) rv[it] = *reinterpret_cast<const float4 *>(a.R + (long)m * a.ldr + nb);
+                        else rv[it] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    }
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int mr = mrow0 + erow + 4 * it;
+                        const f32x4 t = *reinterpret_cast<const f32x4 *>(stg + (erow + 4 * it) * SROW + ecol);
+                        float x[4] = {t[0] + b4.x, t[1] + b4.y, t[2] + b4.z, t[3] + b4.w};
+                        if constexpr (GELU) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) x[r] = gelu_fast(x[r]);
                         }
+                        x[0] += rv[it].x; x[1] += rv[it].y; x[2] += rv[it].z; x[3] += rv[it].w;
+                        if (mr < M) *reinterpret_cast<float4 *>(C + (long)mr * a.ldc + nb) = make_float4(x[0], x[1], x[2], x[3]);
+                    }
+                }
+            } else {
+                // bf16 out: a lane takes 8 columns (one 16-byte store), 8 lanes one row's 64 columns (128 bytes = one line), 8 rows
+                // per instruction — half the store instructions of the 8-byte form, and the stores, not the bytes, bound this tail
+                static_assert(!HAS_R, "bf16 outputs carry no residual");
+                const int erow = lane >> 3, ecol = 8 * (lane & 7), nb = ncol0 + ecol;
+                const float *bp = a.bias ? a.bias + nb : a.epi_zero;
+                const float4 b0 = *reinterpret_cast<const float4 *>(bp), b1 = *reinterpret_cast<const float4 *>(a.bias ? bp + 4 : bp);
+                const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                for (int i8 = 0; i8 < 8; ++i8) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        f32x4 v = acc[i8][j];
+                        v *= a.alpha;
+                        *reinterpret_cast<f32x4 *>(stg + (lane & 15) * SROW + 16 * j + 4 * (lane >> 4)) = v;
+                    }
+                    const int mrow0 = m0 + wr * 128 + i8 * 16;
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) {
+                        const int mr = mrow0 + erow + 8 * it;
+                        const f32x4 t0 = *reinterpret_cast<const f32x4 *>(stg + (erow + 8 * it) * SROW + ecol);
+                        const f32x4 t1 = *reinterpret_cast<const f32x4 *>(stg + (erow + 8 * it) * SROW + ecol + 4);
+                        float x[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+                        unsigned pk[4];
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) {
+                            x[r] += bb[r];
+                            if constexpr (GELU) x[r] = gelu_fast(x[r]);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            __hip_bfloat16 h0 = __float2bfloat16(x[2 * r]), h1 = __float2bfloat16(x[2 * r + 1]);
+                            pk[r] = (unsigned)*reinterpret_cast<bf16_t *>(&h0) | ((unsigned)*reinterpret_cast<bf16_t *>(&h1) << 16);
+                        }
+                        using u32x4n = __attribute__((ext_vector_type(4))) unsigned;
+                        const u32x4n out4 = {pk[0], pk[1], pk[2], pk[3]};
+                        if (FULL || mr < M)  // 60-120 MB read once by the next kernel: streaming stores
+                            __builtin_nontemporal_store(out4, reinterpret_cast<u32x4n *>(C + (long)mr * a.ldc + nb));
                     }
                 }
             }
+            };
+            if (m0 + 256 <= M) epilogue(std::true_type{});
+            else epilogue(std::false_type{});
         }
         m0 = m1;
         n0 = n1;
@@ -818,7 +851,9 @@ void launch_gemm(const GemmArgs &args, DType in, DType out, hipStream_t st) {
     // Q|K and fc1 from M = 6000 on
     const long tiles256 = (long)(a.N / 256) * ceil_div(a.M, 256);
     const bool big = in == DType::BF16 && !a.trans_c && a.K % 64 == 0 && a.K >= 256 && a.N % 256 == 0 && a.nz0 * a.nz1 == 1 &&
-                     a.epi_vec && (a.glds == 8 || a.glds >= 100 || (a.glds == 0 && tiles256 >= 200));
+                     a.epi_vec && (a.glds == 8 || (a.glds == 0 && tiles256 >= 200)) &&
+                     // the epilogue shapes the 256 x 256 kernel is instantiated for; its bf16 rows leave as 16-byte stores
+                     ((out == DType::F32 && a.act == ACT_NONE) || (out == DType::BF16 && !a.R && a.ldc % 8 == 0 && ((uintptr_t)a.C % 16) == 0));
     const int bm = big ? 256 : bm64 ? 64 : 128, bn = big ? 256 : BN;
     dim3 grid(ceil_div(a.N, bn), ceil_div(a.M, bm), a.nz0 * a.nz1);
     MW_CHECK(grid.y <= 65535, "gemm: M too large for grid.y");
@@ -859,17 +894,11 @@ void launch_gemm(const GemmArgs &args, DType in, DType out, hipStream_t st) {
     if (big) {
         // persistent: one workgroup per CU at most, a multiple of 8 so that every XCD's range is walked in step
         const dim3 pgrid((unsigned)std::min<long>(ceil_div<long>((long)grid.x * grid.y, 8) * 8, 256));
-#ifdef MW_GEMM_VARIANTS
-#define V256(v) case 100 + v: if (out == DType::F32) hipLaunchKernelGGL((gemm_bf16_256_kernel<float, v>), pgrid, dim3(512), 0, st, a); \
-                             else hipLaunchKernelGGL((gemm_bf16_256_kernel<bf16_t, v>), pgrid, dim3(512), 0, st, a); break;
-        switch (a.glds) { V256(1) V256(2) V256(3) V256(4) V256(8) V256(12) V256(16) V256(20) V256(28) default:
-#endif
-        if (out == DType::F32) hipLaunchKernelGGL((gemm_bf16_256_kernel<float>), pgrid, dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((gemm_bf16_256_kernel<bf16_t>), pgrid, dim3(512), 0, st, a);
-#ifdef MW_GEMM_VARIANTS
-        }
-#undef V256
-#endif
+        const bool gelu = a.act == ACT_GELU;
+        if (out == DType::F32 && a.R) hipLaunchKernelGGL((gemm_bf16_256_kernel<float, true, false>), pgrid, dim3(512), 0, st, a);
+        else if (out == DType::F32) hipLaunchKernelGGL((gemm_bf16_256_kernel<float, false, false>), pgrid, dim3(512), 0, st, a);
+        else if (gelu) hipLaunchKernelGGL((gemm_bf16_256_kernel<bf16_t, false, true>), pgrid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((gemm_bf16_256_kernel<bf16_t, false, false>), pgrid, dim3(512), 0, st, a);
     } else if (many && out == DType::F32) {
         if (a.trans_c) hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, 128, true, 1>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, 128, false, 1>), grid, dim3(256), 0, st, a);
