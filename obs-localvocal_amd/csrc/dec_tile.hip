@@ -183,6 +183,8 @@ __device__ __forceinline__ void proj_ln_tile(const Proj &p, const float *xin, co
     // weight rows per wave, load instructions per wave (K <= 1280: 160 sixteen-byte pieces per bf16 row, 80 per e4m3 row)
     constexpr int RPW = FR / 8, WJ = (RPW * (W8 ? 80 : 160) + 63) / 64;
     constexpr int TL = FR > 16 ? FR / 16 : 1;                // 16-feature MFMA tiles per workgroup
+    constexpr int MTL = (NB + 15) / 16;                      // 16-row MFMA tiles (2 for the 32-row step: the weights are read once)
+    static_assert(TL * MTL <= 2, "the finishing pass covers two 16 x 16 tiles (32 rows: FR <= 16)");
     uint4 w[WJ];
     const int wpieces = RPW * (K >> (W8 ? 4 : 3));  // 16-byte pieces in the wave's row(s)
     if constexpr (W8) {
@@ -194,8 +196,10 @@ __device__ __forceinline__ void proj_ln_tile(const Proj &p, const float *xin, co
 #pragma unroll
         for (int j = 0; j < WJ; ++j) w[j] = ld_stream16(wbase + 8 * min(lane + 64 * j, wpieces - 1));
     }
-    const int et = tid >> 8, el = (tid & 255) >> 2, er = tid & 3, erow = 4 * (el >> 4) + er;  // finisher: tile, lane, register
-    const int n_e = tile * FR + min(16 * et + (el & 15), FR - 1);
+    // finisher: tile (feature tile when TL = 2, row tile when MTL = 2), lane, register
+    const int et = tid >> 8, el = (tid & 255) >> 2, er = tid & 3;
+    const int etl = TL > 1 ? et : 0, emt = MTL > 1 ? et : 0, erow = 16 * emt + 4 * (el >> 4) + er;
+    const int n_e = tile * FR + min(16 * etl + (el & 15), FR - 1);
     const float bias_e = p.bias ? p.bias[n_e] : 0.0f;
     float ws_e = 1.0f;
     if constexpr (W8) ws_e = p.ws[n_e];
@@ -260,30 +264,40 @@ __device__ __forceinline__ void proj_ln_tile(const Proj &p, const float *xin, co
     if (stamp && tid == 0) stamp[1] = wall_clock64();
     // ---- matrix-core products ----
     {
-        const bf16_t *arow = xs + (fr < n ? fr : 0) * ldxs + 8 * fq;  // rows >= n: any valid row, result ignored
-        const bf16_t *brow = wt + fr * ldxs + 8 * fq;
-        f32x4 acc[TL];
+        const bf16_t *arow[MTL];  // rows >= n: any valid row, result ignored
 #pragma unroll
-        for (int tl = 0; tl < TL; ++tl) acc[tl] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int mt = 0; mt < MTL; ++mt) arow[mt] = xs + (16 * mt + fr < n ? 16 * mt + fr : 0) * ldxs + 8 * fq;
+        const bf16_t *brow = wt + fr * ldxs + 8 * fq;
+        f32x4 acc[MTL][TL];
+#pragma unroll
+        for (int mt = 0; mt < MTL; ++mt)
+#pragma unroll
+            for (int tl = 0; tl < TL; ++tl) acc[mt][tl] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
             const int step = wave + 8 * j, sc = min(step, ksteps - 1);
-            const uint4 af = *reinterpret_cast<const uint4 *>(arow + 32 * sc);
+            uint4 af[MTL];
+#pragma unroll
+            for (int mt = 0; mt < MTL; ++mt) af[mt] = *reinterpret_cast<const uint4 *>(arow[mt] + 32 * sc);
 #pragma unroll
             for (int tl = 0; tl < TL; ++tl) {
                 uint4 wv = *reinterpret_cast<const uint4 *>(brow + 16 * tl * ldxs + 32 * sc);
                 if (step >= ksteps) wv = make_uint4(0, 0, 0, 0);
-                acc[tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8b, af), __builtin_bit_cast(bf16x8b, wv), acc[tl], 0,
-                                                                  0, 0);
+#pragma unroll
+                for (int mt = 0; mt < MTL; ++mt)
+                    acc[mt][tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8b, af[mt]), __builtin_bit_cast(bf16x8b, wv),
+                                                                          acc[mt][tl], 0, 0, 0);
             }
         }
 #pragma unroll
-        for (int tl = 0; tl < TL; ++tl) *reinterpret_cast<f32x4 *>(red + ((tl * 8 + wave) * 64 + lane) * 4) = acc[tl];
+        for (int mt = 0; mt < MTL; ++mt)
+#pragma unroll
+            for (int tl = 0; tl < TL; ++tl) *reinterpret_cast<f32x4 *>(red + (((mt * TL + tl) * 8 + wave) * 64 + lane) * 4) = acc[mt][tl];
     }
     lds_sync();
     if (stamp && tid == 0) stamp[2] = wall_clock64();
     // ---- finish: fixed-order sum of the 8 partial tiles, bias, epilogue ----
-    if (et < TL && erow < n && 16 * et + (el & 15) < FR) {  // tile columns beyond FR come from unwritten LDS rows: ignored
+    if (et < TL * MTL && erow < n && 16 * etl + (el & 15) < FR) {  // tile columns beyond FR come from unwritten LDS rows: ignored
         float r = 0.0f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) r += red[((et * 8 + k) * 64 + el) * 4 + er];
@@ -331,7 +345,9 @@ __device__ __forceinline__ void proj_res_tile(const Proj &p, const bf16_t *xin, 
             const int pc = min(lane + 64 * i, NB * XPR - 1);
             xv[s2][i] = *reinterpret_cast<const u32x4v *>(xin + (long)min(pc / XPR, n - 1) * K + kw + s2 * KC + 8 * (pc % XPR));
         }
-    const int el = (tid & 255) >> 2, er = tid & 3, erow = 4 * (el >> 4) + er, n_e = tile * FR + min(el & 15, FR - 1);
+    constexpr int MTL = (NB + 15) / 16;  // 16-row MFMA tiles (32-row step: two; threads 256.. finish the second)
+    const int el = (tid & 255) >> 2, er = tid & 3, emt = MTL > 1 ? tid >> 8 : 0, erow = 16 * emt + 4 * (el >> 4) + er;
+    const int n_e = tile * FR + min(el & 15, FR - 1);
     const float res_e = e.res[(long)(erow < n ? erow : 0) * p.N + n_e];
     const float bias_v = (p.bias ? p.bias : e.res)[n_e];  // unconditional load: a branch here would split the load block
     const float bias_e = p.bias ? bias_v : 0.0f;
@@ -354,7 +370,9 @@ __device__ __forceinline__ void proj_res_tile(const Proj &p, const bf16_t *xin, 
             *reinterpret_cast<u32x4v *>(xt + (pc / XPR) * XLD + 8 * (pc % XPR)) = xv[0][i];
         }
     }
-    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    f32x4 acc[MTL];
+#pragma unroll
+    for (int mt = 0; mt < MTL; ++mt) acc[mt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     if (stamp && tid == 0) stamp[0] = wall_clock64();
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
@@ -379,19 +397,25 @@ __device__ __forceinline__ void proj_res_tile(const Proj &p, const bf16_t *xin, 
         }
 #pragma unroll
         for (int s2 = 0; s2 < SPC; ++s2) {
-            const uint4 af = *reinterpret_cast<const uint4 *>(xt + (fr < n ? fr : 0) * XLD + (XCH ? 0 : c * KC) + 32 * s2 + 8 * fq);
             const uint4 bfr = *reinterpret_cast<const uint4 *>(wt + fr * LDT + 32 * s2 + 8 * fq);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8b, af), __builtin_bit_cast(bf16x8b, bfr), acc, 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MTL; ++mt) {
+                const int xr = 16 * mt + fr < n ? 16 * mt + fr : 0;
+                const uint4 af = *reinterpret_cast<const uint4 *>(xt + xr * XLD + (XCH ? 0 : c * KC) + 32 * s2 + 8 * fq);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8b, af), __builtin_bit_cast(bf16x8b, bfr), acc[mt], 0,
+                                                                  0, 0);
+            }
         }
     }
     if (stamp && tid == 0) stamp[1] = wall_clock64();
-    *reinterpret_cast<f32x4 *>(red + (wave * 64 + lane) * 4) = acc;
+#pragma unroll
+    for (int mt = 0; mt < MTL; ++mt) *reinterpret_cast<f32x4 *>(red + ((mt * 8 + wave) * 64 + lane) * 4) = acc[mt];
     lds_sync();
     if (stamp && tid == 0) stamp[2] = wall_clock64();
-    if (tid < 256 && erow < n && (el & 15) < FR) {  // tile columns beyond FR come from unwritten LDS rows: ignored
+    if (tid < 256 * MTL && erow < n && (el & 15) < FR) {  // tile columns beyond FR come from unwritten LDS rows: ignored
         float r = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) r += red[(k * 64 + el) * 4 + er];
+        for (int k = 0; k < 8; ++k) r += red[((emt * 8 + k) * 64 + el) * 4 + er];
         if constexpr (W8) r *= ws_e;
         st_agent(e.xout + (long)erow * p.N + n_e, r + bias_e + res_e);
     }
@@ -482,8 +506,14 @@ __device__ __forceinline__ void logits_tile(const bf16_t *W, const unsigned char
     lds_sync();
     // ---- the wave's tile over all of K: chunk c from the ring -> private LDS tile -> 4 MFMA steps ----
     bf16_t *wt = wtile + wave * 16 * LLD;
-    const bf16_t *arow = xs + (fr < n ? fr : 0) * ldxs + 8 * fq;
-    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    constexpr int MTL = (NB + 15) / 16;  // 16-row MFMA tiles
+    const bf16_t *arow[MTL];
+    f32x4 acc[MTL];
+#pragma unroll
+    for (int mt = 0; mt < MTL; ++mt) {
+        arow[mt] = xs + (16 * mt + fr < n ? 16 * mt + fr : 0) * ldxs + 8 * fq;
+        acc[mt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
 #pragma unroll
@@ -504,17 +534,23 @@ __device__ __forceinline__ void logits_tile(const bf16_t *W, const unsigned char
         }
 #pragma unroll
         for (int s2 = 0; s2 < 4; ++s2) {
-            const uint4 af = *reinterpret_cast<const uint4 *>(arow + c * LKC + 32 * s2);
             const uint4 bfr = *reinterpret_cast<const uint4 *>(wt + fr * LLD + 32 * s2 + 8 * fq);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8b, af), __builtin_bit_cast(bf16x8b, bfr), acc, 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MTL; ++mt) {
+                const uint4 af = *reinterpret_cast<const uint4 *>(arow[mt] + c * LKC + 32 * s2);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8b, af), __builtin_bit_cast(bf16x8b, bfr), acc[mt], 0,
+                                                                  0, 0);
+            }
         }
     }
-    // lane holds rows 4*fq + r of vocabulary entry f0 + fr
+    // lane holds rows 16*mt + 4*fq + r of vocabulary entry f0 + fr
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = 4 * fq + r;
-        if (row < n && f0 + fr < N) out[(long)row * ldo + f0 + fr] = W8 ? acc[r] * ws_e : acc[r];
-    }
+    for (int mt = 0; mt < MTL; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * mt + 4 * fq + r;
+            if (row < n && f0 + fr < N) out[(long)row * ldo + f0 + fr] = W8 ? acc[mt][r] * ws_e : acc[mt][r];
+        }
 }
 
 // ---- self-attention as a kernel of its own, straight-line: three dependent load levels and no more ----
@@ -854,14 +890,14 @@ __global__ __launch_bounds__(MT) void proj_ln_tile_kernel(Proj p, const float *x
                                                                      Epi e) {
     __shared__ __attribute__((aligned(16))) bf16_t xs[NB * (256 * LN_MAX_F4 + 8)];
     __shared__ __attribute__((aligned(16))) bf16_t wt[FR * (256 * LN_MAX_F4 + 8)];
-    __shared__ __attribute__((aligned(16))) float red[(FR > 16 ? FR / 16 : 1) * 8 * 64 * 4];
+    __shared__ __attribute__((aligned(16))) float red[(FR > 16 ? FR / 16 : 1) * ((NB + 15) / 16) * 8 * 64 * 4];
     proj_ln_tile<NB, EPI, FR, DESC, W8>(p, xin, ln_w, ln_b, n, e, xs, wt, red, nullptr);
 }
 
 template <int NB, int SPC, int CH, int FR, bool W8>
 __global__ __launch_bounds__(MT) void proj_res_tile_kernel(Proj p, const bf16_t *xin, int n, Epi e) {
     __shared__ __attribute__((aligned(16))) bf16_t lds_t[8 * (16 * (32 * SPC + 8) + NB * ((NB > 8 ? 1 : CH) * 32 * SPC + 8))];
-    __shared__ __attribute__((aligned(16))) float red[8 * 64 * 4];
+    __shared__ __attribute__((aligned(16))) float red[((NB + 15) / 16) * 8 * 64 * 4];
     proj_res_tile<NB, SPC, CH, FR, W8>(p, xin, n, e, lds_t, red, nullptr);
 }
 
@@ -906,7 +942,7 @@ __global__ __launch_bounds__(256) void step_begin_batch_kernel(const StepBlock *
 // passes) for fc1.  Rows: kernels are instantiated for 1, 5 (beam step) and 16 (batched step) rows.
 namespace {
 void launch_proj_impl(const GemvArgs &a, const StepRow *rows, long kv_layer_off, hipStream_t st) {
-    MW_CHECK(a.x && a.W && a.out && a.n >= 1 && a.n <= STEP_MAX_ROWS, "proj_wg: 1..16 rows");
+    MW_CHECK(a.x && a.W && a.out && a.n >= 1 && a.n <= STEP_MAX_ROWS, "proj_wg: 1..32 rows");
     MW_CHECK(a.N % 32 == 0 && a.K % 32 == 0 && a.ldx == a.K && !a.d_rows, "proj_wg: shape");
     const bool ln = a.ln_w != nullptr;
     Proj p{(const bf16_t *)a.W, a.bias, a.N, a.K, (const unsigned char *)a.W8, a.w_scale};
@@ -921,8 +957,8 @@ void launch_proj_impl(const GemvArgs &a, const StepRow *rows, long kv_layer_off,
         if (a.N <= 1280)                                                                                                            \
             hipLaunchKernelGGL((proj_ln_tile_kernel<NBv, EPIv, 8, DESCv, W8v>), dim3(a.N / 8), block, 0, st, p, (const float *)a.x, \
                                a.ln_w, a.ln_b, a.n, e);                                                                             \
-        else if (a.N > 4096)                                                                                                        \
-            hipLaunchKernelGGL((proj_ln_tile_kernel<NBv, EPIv, 32, DESCv, W8v>), dim3(a.N / 32), block, 0, st, p,                   \
+        else if (a.N > 4096 && NBv <= 16)                                                                                           \
+            hipLaunchKernelGGL((proj_ln_tile_kernel<(NBv <= 16 ? NBv : 16), EPIv, 32, DESCv, W8v>), dim3(a.N / 32), block, 0, st, p, \
                                (const float *)a.x, a.ln_w, a.ln_b, a.n, e);                                                         \
         else                                                                                                                        \
             hipLaunchKernelGGL((proj_ln_tile_kernel<NBv, EPIv, 16, DESCv, W8v>), dim3(a.N / 16), block, 0, st, p,                   \
@@ -932,7 +968,8 @@ void launch_proj_impl(const GemvArgs &a, const StepRow *rows, long kv_layer_off,
     do {                                                      \
         if (a.n == 1) MW_PROJ_LN(1, EPIv, DESCv, W8v);        \
         else if (a.n <= 5) MW_PROJ_LN(5, EPIv, DESCv, W8v);   \
-        else MW_PROJ_LN(16, EPIv, DESCv, W8v);                \
+        else if (a.n <= 16) MW_PROJ_LN(16, EPIv, DESCv, W8v); \
+        else MW_PROJ_LN(32, EPIv, DESCv, W8v);                \
     } while (0)
 #define MW_PROJ_LN_NB(EPIv, DESCv) MW_PROJ_LN_W(EPIv, DESCv, false)
     if (ln) MW_CHECK(a.ln_b && a.K <= 256 * LN_MAX_F4, "proj_wg: LayerNorm classes need K <= 1280");
@@ -976,7 +1013,8 @@ void launch_proj_impl(const GemvArgs &a, const StepRow *rows, long kv_layer_off,
     do {                                          \
         if (a.n == 1) MW_RES_CH(1, SPCv);         \
         else if (a.n <= 5) MW_RES_CH(5, SPCv);    \
-        else MW_RES_CH(16, SPCv);                 \
+        else if (a.n <= 16) MW_RES_CH(16, SPCv);  \
+        else MW_RES_CH(32, SPCv);                 \
     } while (0)
         switch (spc) {
         case 2: MW_RES_SPC(2); break;
@@ -1033,7 +1071,7 @@ void launch_cross_attn_batch(const float *q, const StepBlock *blk, long k_off, l
     const dim3 grid(n_groups * H * splits), block(MT);
     // the kernel variant goes by the rows of ONE request (a workgroup serves one request): <= 5 (the beams of a stream, one
     // row of a greedy stream) unless a prompt of up to 16 tokens rides in the step
-    MW_CHECK(max_group_rows >= 1 && max_group_rows <= n_rows, "cross_attn_batch: rows per request");
+    MW_CHECK(max_group_rows >= 1 && max_group_rows <= n_rows && max_group_rows <= STEP_MAX_REQ_ROWS, "cross_attn_batch: rows per request");
     if (max_group_rows <= 5)
         hipLaunchKernelGGL((cross_attn_lean_kernel<5, bf16_t, true>), grid, block, 0, st, q, (const bf16_t *)nullptr, (const bf16_t *)nullptr,
                            blk->groups, k_off, v_off, partial, (bf16_t *)out, head_cnt, 0, H, d, 0, splits);
@@ -1068,7 +1106,8 @@ void launch_logits_tile(const GemvArgs &a, hipStream_t st) {
     do {                                    \
         if (a.n == 1) MW_LT(1, NCHv);       \
         else if (a.n <= 5) MW_LT(5, NCHv);  \
-        else MW_LT(16, NCHv);               \
+        else if (a.n <= 16) MW_LT(16, NCHv); \
+        else MW_LT(32, NCHv);               \
     } while (0)
     switch (a.K / LKC) {
     case 3: MW_LT_NB(3); break;

@@ -202,6 +202,7 @@ std::shared_ptr<Hub> create_hub(const Model &m, int device, bool use_graphs) {
     // lanes and collapsed throughput 30x with three or more (64 turbo streams: 4266 audio-s/s -> 151): HIP keeps a separate,
     // smaller pool of hardware queues per priority class.
     if (const char *e = getenv("MI355_WHISPER_LANES")) h->n_lanes = std::max(1, std::min(Hub::N_LANES, atoi(e)));
+    if (const char *e = getenv("MI355_WHISPER_GATHER_US")) h->gather_us = std::max(0, std::min(2000, atoi(e)));
     for (int li = 0; li < h->n_lanes; ++li) {
         Hub::Lane &ln = h->lanes[li];
         MW_HIP(hipStreamCreateWithFlags(&ln.st, hipStreamNonBlocking));
@@ -407,13 +408,15 @@ void Hub::run_encode(EncLane &ln, const std::vector<EncRequest *> &batch) {
 void Hub::submit(StepRequest &r) {
     std::unique_lock<std::mutex> lk(mu);
     queue.push_back(&r);
+    hot[r.c] = now_ms();
+    if (n_gathering > 0) cv_gather.notify_all();
     auto idle_lane = [&]() -> Lane * {
         for (int li = 0; li < n_lanes; ++li)
             if (!lanes[li].busy) return &lanes[li];
         return nullptr;
     };
     while (!r.done) {
-        Lane *lane = r.taken ? nullptr : idle_lane();
+        Lane *lane = (r.taken || n_gathering > 0) ? nullptr : idle_lane();  // (one leader gathers at a time: it will take or wake us)
         if (!lane) {
             // every lane is busy, or this request is already part of a running step: sleep on the REQUEST's condition variable.
             // Wake-ups are targeted (the requests of a finished step; the owner of the oldest queued request when a lane is
@@ -424,6 +427,25 @@ void Hub::submit(StepRequest &r) {
         }
         // a lane is idle: this thread leads the next step on it.  It takes the oldest request and every later one that can
         // share its step (same rules, rows / groups / logits rows / sampler rows within the step's limits), in order.
+        lane->busy = true;  // (this thread leads on it from here on)
+        if (gather_us > 0 && !r.solo) {
+            // streams that asked for a step within the last 2 ms and are neither queued nor inside a running step are about to
+            // ask again: wait for them, at most gather_us
+            auto expected = [&]() {
+                const double t = now_ms();
+                int n = 0;
+                for (auto it = hot.begin(); it != hot.end();) {
+                    if (t - it->second > 2.0) it = hot.erase(it);
+                    else ++n, ++it;
+                }
+                return n - n_running;
+            };
+            const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(gather_us);
+            n_gathering += 1;
+            while ((int)queue.size() < std::min(expected(), STEP_MAX_GROUPS) && cv_gather.wait_until(lk, deadline) != std::cv_status::timeout) {
+            }
+            n_gathering -= 1;
+        }
         std::vector<StepRequest *> batch;
         int rows = 0, lrows = 0, srows = 0;
         StepRequest *first = queue.front();
@@ -444,7 +466,7 @@ void Hub::submit(StepRequest &r) {
                 ++it;
             }
         }
-        lane->busy = true;
+        n_running += (int)batch.size();
         if (!queue.empty() && idle_lane()) queue.front()->cv.notify_one();  // more work and another lane free: next leader
         lk.unlock();
         std::exception_ptr err;
@@ -463,6 +485,7 @@ void Hub::submit(StepRequest &r) {
         n_steps += 1;
         n_rows += (unsigned long long)rows;
         n_requests += batch.size();
+        n_running -= (int)batch.size();
         lane->busy = false;
         // the lane is free again: unless this thread leads the next step itself (its own request is still queued), hand the
         // lead to the owner of the oldest queued request
@@ -901,14 +924,14 @@ void decode(Context &c, const int *tokens, const int *pos, const int *slot, int 
         MW_CHECK(slot[i] >= 0 && slot[i] < KV_SLOTS, "decode: bad sequence slot");
     }
     for (int i = 0; i < n_logit_rows; ++i) MW_CHECK(logit_rows[i] >= 0 && logit_rows[i] < n, "decode: bad logits row");
-    if (c.tile_step && c.use_hub && c.model.hub && (!c.ps_armed || c.ps_n <= STEP_MAX_ROWS)) {
+    if (c.tile_step && c.use_hub && c.model.hub && (!c.ps_armed || c.ps_n <= STEP_MAX_REQ_ROWS)) {
         // batched path: the step runs on the hub of the contexts that share these weights, together with whatever other
-        // contexts have queued meanwhile (one pass over the weights for all their rows).  A call of more than STEP_MAX_ROWS
+        // contexts have queued meanwhile (one pass over the weights for all their rows).  A call of more than STEP_MAX_REQ_ROWS
         // rows (a long prompt: initial_prompt / prompt_past, whisper-processing.cpp:191-199) goes through in chunks of
-        // STEP_MAX_ROWS consecutive rows, one step each — one pass over the weights per 16 tokens on the matrix-core tile
+        // STEP_MAX_REQ_ROWS consecutive rows, one step each — one pass over the weights per 16 tokens on the matrix-core tile
         // kernels; a chunk's rows see the K / V of the chunks before it through the cache (a kernel boundary apart).
         const bool want_sample = c.ps_armed && c.fuse_sample && n_logit_rows > 0 && c.prof_tag < 0;
-        const int n_chunks = ceil_div(n, STEP_MAX_ROWS), last0 = (n_chunks - 1) * STEP_MAX_ROWS;
+        const int n_chunks = ceil_div(n, STEP_MAX_REQ_ROWS), last0 = (n_chunks - 1) * STEP_MAX_REQ_ROWS;
         bool chunkable = n_chunks == 1 || (c.prof_tag < 0 && c.dup_tag < 0 && c.use_graphs);
         if (n_chunks > 1) {
             // logits rows in call order (the copies below land them in that order); a fused sampler wants them all in the
@@ -922,8 +945,8 @@ void decode(Context &c, const int *tokens, const int *pos, const int *slot, int 
             int lr_done = 0;
             bool fused = false;
             for (int ch = 0; ch < n_chunks; ++ch) {
-                const int r0 = ch * STEP_MAX_ROWS, nr = std::min(STEP_MAX_ROWS, n - r0);
-                int lrows[STEP_MAX_ROWS], nl = 0;
+                const int r0 = ch * STEP_MAX_REQ_ROWS, nr = std::min(STEP_MAX_REQ_ROWS, n - r0);
+                int lrows[STEP_MAX_REQ_ROWS], nl = 0;
                 for (int i = 0; i < n_logit_rows; ++i)
                     if (logit_rows[i] >= r0 && logit_rows[i] < r0 + nr) lrows[nl++] = logit_rows[i] - r0;
                 StepRequest r;

@@ -7,6 +7,7 @@
 
 #include <condition_variable>
 #include <deque>
+#include <unordered_map>
 #include <exception>
 #include <memory>
 #include <mutex>
@@ -110,6 +111,14 @@ struct Hub {
     bool use_graphs = true;
     std::mutex mu;
     std::deque<StepRequest *> queue;
+    // Gathering: a leader that finds fewer requests queued than streams are decoding right now gives the others a moment to
+    // arrive (their host-side bookkeeping between two steps takes tens of microseconds) before it closes the step — 8 greedy
+    // streams otherwise drifted apart and rode 2.4 rows per step on two lanes.  `hot`: when a context last asked for a step;
+    // `n_running`: requests inside steps that are running now.  A stream alone (nobody else hot) never waits.
+    std::unordered_map<const Context *, double> hot;
+    int n_running = 0, n_gathering = 0;
+    std::condition_variable cv_gather;
+    int gather_us = 100;  // MI355_WHISPER_GATHER_US (0: take what is queued)
     // statistics (mw_hub_stats)
     unsigned long long n_steps = 0, n_rows = 0, n_requests = 0, n_enc_passes = 0, n_enc_windows = 0;
     // encoder passes of the same contexts, batched the same way on a stream of their own: the windows of up to

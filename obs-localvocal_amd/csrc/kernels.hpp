@@ -105,8 +105,11 @@ constexpr int CROSS_PART_STRIDE = 96;
 // requests (one request = the rows of one stream context: its beams, or the tokens of a short prompt).  Everything that
 // differs per row or per request travels in a StepBlock in device memory, so one captured graph serves any mix of
 // contexts with the same (rows, groups, logits rows) shape.
-constexpr int STEP_MAX_ROWS = 16;
-constexpr int STEP_MAX_GROUPS = 16;
+constexpr int STEP_MAX_ROWS = 32;
+constexpr int STEP_MAX_GROUPS = 32;
+// rows of ONE request in a step (the beams of a stream, or a chunk of a prompt): what the cross-attention kernel, whose
+// workgroups serve one request each, is instantiated for
+constexpr int STEP_MAX_REQ_ROWS = 16;
 struct StepRow {
     bf16_t *kself, *vself;  // self K / V cache of the row's context, layer 0: [L][KV_SLOTS][n_text_ctx][d]
     const int *kv_idx;      // the context's current index table [KV_SLOTS][n_text_ctx]

@@ -17,11 +17,13 @@ for W in 1 8 16; do
   timeout -s KILL 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/p_mfma$W -o m -- python3 tools/encoder_profile.py large-v3 2 $W > $OUT/encoder_w$W.log 2>&1
   python3 tools/pmc_by_grid.py $(find /tmp/p_mfma$W -name "*counter_collection.csv") > $OUT/pmc_encoder_mfma_w$W.txt
 done
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_streams -o s -- python3 bench.py --workload streams --steps 2 --warmup 1 --concurrency 64 > $OUT/streams_under_profiler.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_streams -o s -- python3 bench.py --workload streams --steps 2 --warmup 1 > $OUT/streams_under_profiler.log 2>&1
 cp $(find /tmp/p_streams -name "*kernel_stats.csv") $OUT/kernel_stats_streams64_turbo.csv
 timeout -k 10 300 python3 bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err
 timeout -k 10 300 python3 bench.py --precision fp8 > $OUT/bench_line_fp8.json 2> $OUT/bench_line_fp8.err
-timeout -k 10 300 python3 bench.py --workload streams --steps 3 --warmup 1 --concurrency 64 > $OUT/bench_line_streams64.json 2> $OUT/bench_line_streams64.err
+timeout -k 10 300 python3 bench.py --workload streams --steps 3 --warmup 1 > $OUT/bench_line_streams64.json 2> $OUT/bench_line_streams64.err
+# the single-GPU proxy of the 8-GPU strong-scaling case: 64 streams / 8 GPUs = 8 streams per GPU
+timeout -k 10 300 python3 bench.py --workload streams --streams 8 --steps 3 --warmup 1 > $OUT/bench_line_streams8.json 2> $OUT/bench_line_streams8.err
 timeout -k 10 200 python3 tools/streaming_latency.py > $OUT/streaming_latency_bf16.json 2> /dev/null
 timeout -k 10 200 python3 tools/streaming_latency.py --precision fp8 > $OUT/streaming_latency_fp8.json 2> /dev/null
 timeout -k 10 100 python3 tools/silero_bench.py > $OUT/silero_vad_timing.txt 2>&1
