@@ -47,8 +47,9 @@ int mw_hparams(struct whisper_context *ctx, int32_t out[11]);
 int mw_pcm_to_mel(struct whisper_context *ctx, const float *samples, int n_samples);
 /* same, PCM already resident in HBM (the timed region of bench.py starts here) */
 int mw_pcm_to_mel_device(struct whisper_context *ctx, const float *samples_device, int n_samples);
-/* The same log-mel for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that
-   forbid hipMalloc).  No counterpart in the reference.  Calls no hipMalloc / hipFree / allocating routine: the
+/* The same log-mel for callers that cannot allocate (tight serving loops, harnesses that forbid hipMalloc, code that
+   must not disturb an allocator while another thread captures a HIP graph).  The call itself cannot be captured: it
+   launches on the context's own stream and synchronises that stream before it returns.  No counterpart in the reference.  Calls no hipMalloc / hipFree / allocating routine: the
    intermediate rows and the global-maximum word live in a static __device__ array of the library (1.54 MB per GPU, held
    until the process ends).  Input and output are the caller's device buffers: samples_device[n_samples] ->
    mel_out_device[n_len][n_mel] fp32, frame-major (the engine's HBM layout, the transpose of mw_get_mel's),

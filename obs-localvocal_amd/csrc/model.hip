@@ -414,8 +414,9 @@ void load_model(Model &m, const unsigned char *data, size_t size, DType wt, hipS
     size_t vec_elems = (size_t)hp.n_audio_ctx * d + (size_t)hp.n_text_ctx * d + 2 * d + Le * (2 * d + d + d + 4 * d + d + 4 * d) +
                        Ld * (3 * d + d + d + d + 4 * d + d + 6 * d + 2 * d) + 4 * d + 64;
     m.arena_size = mat_elems * ws + vec_elems * 4 + (64 + 16 * (Le + Ld)) * 256 + (1 << 20);
-    if (fp8)  // e4m3 copies + row scales of the decoder projections and the logits matrix
-        m.arena_size += Ld * 12 * d * d + (size_t)hp.n_vocab * d + (Ld * 12 * d + hp.n_vocab) * 4 + (4 + 12 * Ld) * 256;
+    if (fp8)  // e4m3 copies + row scales of the decoder projections and the logits matrix: per layer Wq|Wk|Wv (3 d^2), the two
+              // attention outputs and cross-q (3 d^2), fc1 and fc2 (8 d^2) = 14 d^2 bytes and 3 + 3 + 4 + 1 = 11 d scales
+        m.arena_size += Ld * 14 * d * d + (size_t)hp.n_vocab * d + (Ld * 11 * d + hp.n_vocab) * 4 + (4 + 12 * Ld) * 256;
     m.dec_fp8 = fp8;
     MW_HIP(hipMalloc((void **)&m.arena, m.arena_size));
     m.arena_owner = std::shared_ptr<void>(m.arena, free_device_block);

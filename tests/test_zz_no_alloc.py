@@ -45,6 +45,16 @@ def test_no_alloc_mel_equals_existing_entry_point_twice_second_smaller(pkg, mode
         for eng, pcm in calls:
             pcm = np.ascontiguousarray(pcm, dtype=np.float32)
             got = _noalloc_mel(pkg, eng, pcm)
+            # the call allocates nothing on the device: free memory is the same before and after a second, identical call
+            # (inputs and outputs of _noalloc_mel are torch's, allocated from its caching pool before the call)
+            x = torch.from_numpy(pcm).cuda()
+            out = torch.empty(got.size + 17, dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()
+            free0 = torch.cuda.mem_get_info()[0]
+            n_len = C.c_int(-1)
+            assert eng.L.mw_pcm_to_mel_noalloc(eng.ctx, C.c_void_p(x.data_ptr()), len(pcm), C.c_void_p(out.data_ptr()), out.numel(),
+                                               C.byref(n_len)) == 0
+            assert torch.cuda.mem_get_info()[0] == free0
             want = eng.mel(pcm)                       # existing entry points: [n_mel][n_len]
             assert got.shape == want.T.shape
             assert np.array_equal(got, want.T), float(np.abs(got - want.T).max())
