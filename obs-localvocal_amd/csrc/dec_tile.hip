@@ -130,7 +130,7 @@ constexpr int LN_MAX_F4 = 5;  // float4 per lane of a LayerNorm row: K <= 1280
 // is unconditional (clamped address, value selected afterwards) and issued before the first wait.  A load
 // under a predicate becomes a branch with `s_waitcnt vmcnt(0)` at its join; in proj_phase that put the weight
 // loads first and then five serialised (row, gamma, beta) round trips in front of the LayerNorm — 3 to 4 us
-// of a 5 us kernel (tools/microbench/mb_phases).
+// of a 5 us kernel (wall_clock64 stamps through the `stamp` argument below).
 template <int EPI>
 __device__ __forceinline__ void proj_finish(float v, int erow, int n_e, const Proj &p, const Epi &e, float res_e) {
     if constexpr (EPI == EPI_QKV) {
