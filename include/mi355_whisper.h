@@ -19,14 +19,18 @@ extern "C" {
 enum mw_precision {
     MW_PRECISION_BF16 = 0, /* bf16 weights / MFMA operands / KV caches, fp32 accumulate + residual stream */
     MW_PRECISION_FP32 = 1, /* exact fp32 everywhere (f32 MFMA): the bit-exact-token mode for tiny/base */
-    MW_PRECISION_FP8 = 2   /* MW_PRECISION_BF16 with the decoder's projection matrices and the logits matrix quantised to OCP
+    MW_PRECISION_FP8 = 2,  /* MW_PRECISION_BF16 with the decoder's projection matrices and the logits matrix quantised to OCP
                               e4m3 at load (one power-of-two scale per output row) and streamed as bytes by the decode-step
                               kernels (bf16 activations, fp32 accumulate); the encoder keeps bf16 weights */
+    MW_PRECISION_FP8_MX = 3 /* MW_PRECISION_FP8 and, in the encoder, the Q|K, fc1 and fc2 products of every block in MX-fp8 on
+                              the fp8 matrix cores: weights AND activations as e4m3 with one power-of-two scale per block of
+                              32 along k (OCP microscaling; scale = the smallest power of two that brings the block under
+                              448, round to nearest even).  Needs n_audio_state % 256 == 0 (base, small, medium, large) */
 };
 
 /* Same as whisper_init_from_file_with_params (whisper-processing.cpp:112) with the arithmetic mode made
    explicit.  whisper_init_* use MW_PRECISION_BF16 unless the environment variable
-   MI355_WHISPER_PRECISION is "fp32" or "fp8". */
+   MI355_WHISPER_PRECISION is "fp32", "fp8" or "fp8mx". */
 struct whisper_context *mw_init_from_file(const char *path_model, int gpu_device, int precision);
 struct whisper_context *mw_init_from_buffer(const void *buffer, size_t size, int gpu_device, int precision);
 /* A further context (one more audio stream / OBS source) on src's GPU that SHARES src's HBM-resident weights: nothing is
@@ -60,6 +64,15 @@ int mw_pcm_to_mel_device(struct whisper_context *ctx, const float *samples_devic
 int mw_pcm_to_mel_noalloc(struct whisper_context *ctx, const float *samples_device, int n_samples, float *mel_out_device,
                           size_t mel_out_floats, int *n_len_out);
 int mw_mel_n_len(struct whisper_context *ctx);
+/* MX-fp8 stages of MW_PRECISION_FP8_MX on host arrays (parity entry points; the encoder chains the same kernels inside
+   whisper_full, whisper-processing.cpp:218-219).  epilogue: 0 = bf16 rows (+ bias), 1 = fp32 rows + bias + residual R,
+   2 = GELU(+ bias) re-quantised to MX-fp8 (returned decoded).  A [M][K] and W [N][K] are quantised by the library's kernels
+   (W from its bf16 rounding, as the loader does) and handed back decoded when the pointers are given; C_out is [M][N]
+   fp32.  K % 128 == 0, N % 256 == 0. */
+int mw_mx_gemm(int device, const float *A, int M, int K, const float *W, int N, const float *bias, const float *R, int epilogue,
+               float *C_out, float *A_decoded, float *W_decoded);
+/* LayerNorm (ggml_norm + weight, bias) whose rows leave as MX-fp8 (returned decoded) and, optionally, as bf16; d % 256 == 0 */
+int mw_mx_layernorm(int device, const float *x, const float *w, const float *b, int rows, int d, float *out_decoded, float *out_bf16);
 /* whisper_full (whisper-processing.cpp:218-219) with the PCM already resident in HBM on the context's device */
 int mw_full_device(struct whisper_context *ctx, struct whisper_full_params params, const float *samples_device,
                    int n_samples);

@@ -25,6 +25,7 @@ CSRC = os.path.join(_HERE, "csrc")
 PRECISION_BF16 = 0
 PRECISION_FP32 = 1
 PRECISION_FP8 = 2
+PRECISION_FP8_MX = 3
 SAMPLING_GREEDY = 0
 SAMPLING_BEAM_SEARCH = 1
 
@@ -104,7 +105,7 @@ EXPORTED_SYMBOLS = [
     "whisper_token_nosp", "whisper_token_not", "whisper_token_beg", "whisper_token_lang", "whisper_token_translate",
     "whisper_token_transcribe", "whisper_tokenize",
     "mw_full_device", "mw_profile_begin", "mw_profile_end",
-    "mw_init_from_file", "mw_init_from_buffer", "mw_init_shared", "mw_hparams", "mw_pcm_to_mel", "mw_pcm_to_mel_device", "mw_pcm_to_mel_noalloc", "mw_mel_n_len",
+    "mw_init_from_file", "mw_init_from_buffer", "mw_init_shared", "mw_hparams", "mw_pcm_to_mel", "mw_pcm_to_mel_device", "mw_pcm_to_mel_noalloc", "mw_mel_n_len", "mw_mx_gemm", "mw_mx_layernorm",
     "mw_get_mel", "mw_encode", "mw_get_encoder_out", "mw_get_cross_kv", "mw_decode", "mw_decode_rows", "mw_get_logits", "mw_kv_clear",
     "mw_process_logits", "mw_get_timings", "mw_reset_timings", "mw_stream", "mw_synchronize",
     "mw_set_force_decode_steps", "mw_hub_stats", "mw_set_duplicate_class", "mw_bench_decode_step", "mw_bench_mel", "mw_bench_encode", "mw_last_error",
@@ -205,6 +206,9 @@ def lib():
     L.mw_pcm_to_mel.argtypes = [P, FP, C.c_int]
     L.mw_pcm_to_mel_device.argtypes = [P, P, C.c_int]
     L.mw_pcm_to_mel_noalloc.argtypes = [P, P, C.c_int, P, C.c_size_t, C.POINTER(C.c_int)]
+    FPm = C.POINTER(C.c_float)
+    L.mw_mx_gemm.argtypes = [C.c_int, FPm, C.c_int, C.c_int, FPm, C.c_int, FPm, FPm, C.c_int, FPm, FPm, FPm]
+    L.mw_mx_layernorm.argtypes = [C.c_int, FPm, FPm, FPm, C.c_int, C.c_int, FPm, FPm]
     L.mw_mel_n_len.argtypes = [P]
     L.mw_full_device.argtypes = [P, FullParams, P, C.c_int]
     L.mw_get_mel.argtypes = [P, FP]
@@ -703,3 +707,40 @@ def remove_leading_trailing_nonalpha(s: bytes) -> bytes:
     buf = C.create_string_buffer(len(s) + 8)
     lib().lv_remove_leading_trailing_nonalpha(s, buf, len(buf))
     return buf.value
+
+
+
+MXE_BF16, MXE_F32_RES, MXE_MX_GELU = 0, 1, 2
+
+
+def mx_gemm(A, W, bias=None, R=None, epilogue=MXE_BF16, device=0):
+    """The MX-fp8 product of MW_PRECISION_FP8_MX on host arrays (mw_mx_gemm): returns (C [M][N] fp32, A decoded, W decoded)."""
+    L = lib()
+    A = np.ascontiguousarray(A, dtype=np.float32)
+    W = np.ascontiguousarray(W, dtype=np.float32)
+    M, K = A.shape
+    N = W.shape[0]
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float)) if a is not None else None  # noqa: E731
+    b = None if bias is None else np.ascontiguousarray(bias, dtype=np.float32)
+    r = None if R is None else np.ascontiguousarray(R, dtype=np.float32)
+    out, ad, wd = np.empty((M, N), np.float32), np.empty((M, K), np.float32), np.empty((N, K), np.float32)
+    rc = L.mw_mx_gemm(device, fp(A), M, K, fp(W), N, fp(b), fp(r), epilogue, fp(out), fp(ad), fp(wd))
+    if rc != 0:
+        raise RuntimeError(f"mw_mx_gemm failed ({rc}): {last_error()}")
+    return out, ad, wd
+
+
+def mx_layernorm(x, w, b, with_bf16=True, device=0):
+    """LayerNorm with MX-fp8 rows out (mw_mx_layernorm): returns (decoded MX rows, bf16 rows or None)."""
+    L = lib()
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    rows, d = x.shape
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float)) if a is not None else None  # noqa: E731
+    out = np.empty((rows, d), np.float32)
+    hb = np.empty((rows, d), np.float32) if with_bf16 else None
+    rc = L.mw_mx_layernorm(device, fp(x), fp(w), fp(b), rows, d, fp(out), fp(hb))
+    if rc != 0:
+        raise RuntimeError(f"mw_mx_layernorm failed ({rc}): {last_error()}")
+    return out, hb

@@ -56,16 +56,18 @@ template <typename F> int guarded(const char *what, F &&f) {
 // additionally kept (and streamed) as e4m3
 struct Precision {
     DType wt;
-    bool fp8;
+    int fp8;  // 0, 1 = e4m3 decoder weights, 2 = that + the MX-fp8 encoder products
     bool operator==(const Precision &o) const { return wt == o.wt && fp8 == o.fp8; }
 };
 Precision precision_of(int mw_precision) {
-    return Precision{mw_precision == MW_PRECISION_FP32 ? DType::F32 : DType::BF16, mw_precision == MW_PRECISION_FP8};
+    return Precision{mw_precision == MW_PRECISION_FP32 ? DType::F32 : DType::BF16,
+                     mw_precision == MW_PRECISION_FP8_MX ? 2 : mw_precision == MW_PRECISION_FP8 ? 1 : 0};
 }
 Precision default_precision() {
     const char *e = getenv("MI355_WHISPER_PRECISION");
     if (e && (strcmp(e, "fp32") == 0 || strcmp(e, "f32") == 0)) return precision_of(MW_PRECISION_FP32);
     if (e && (strcmp(e, "fp8") == 0 || strcmp(e, "f8") == 0)) return precision_of(MW_PRECISION_FP8);
+    if (e && (strcmp(e, "fp8mx") == 0 || strcmp(e, "mxfp8") == 0)) return precision_of(MW_PRECISION_FP8_MX);
     return precision_of(MW_PRECISION_BF16);
 }
 
@@ -726,6 +728,111 @@ int mw_bench_decode_step(struct whisper_context *ctx, int rows, int n_past, int 
         return 0;
     });
 }
+// ---- MX-fp8 stage entries (include/mi355_whisper.h): the quantisers, the LayerNorm producer and the product of gemm_mx.hip
+// on host arrays, for the parity tests; operands come back decoded (e4m3 byte x 2^(scale - 127)) ----
+namespace {
+float e4m3_decode(unsigned char v) {
+    const int s = v >> 7, e = (v >> 3) & 15, mnt = v & 7;
+    float x = e == 0 ? ldexpf((float)mnt, -9) : (e == 15 && mnt == 7) ? NAN : ldexpf(1.0f + mnt / 8.0f, e - 7);
+    return s ? -x : x;
+}
+struct DevBuf {
+    void *p = nullptr;
+    explicit DevBuf(size_t n) { MW_HIP(hipMalloc(&p, std::max<size_t>(n, 16))); }
+    ~DevBuf() { (void)hipFree(p); }
+    DevBuf(const DevBuf &) = delete;
+    float *f() { return (float *)p; }
+    unsigned char *u8() { return (unsigned char *)p; }
+};
+void decode_rows(const std::vector<unsigned char> &q, const std::vector<unsigned char> &s, int rows, int K, bool act, float *out) {
+    const int RB = act ? mx_row_blocks_a(rows) : rows / 64;
+    for (int r = 0; r < rows; ++r)
+        for (int k = 0; k < K; ++k) {
+            const int sb = s[act ? mx_sa_off(r, k >> 5, RB) : mx_sw_off(r, k >> 5, RB)];
+            out[(size_t)r * K + k] = e4m3_decode(q[(size_t)r * K + k]) * ldexpf(1.0f, sb - 127);
+        }
+}
+}  // namespace
+int mw_mx_gemm(int device, const float *A, int M, int K, const float *W, int N, const float *bias, const float *R, int epilogue, float *C_out,
+               float *A_decoded, float *W_decoded) {
+    if (!A || !W || !C_out || M <= 0 || N <= 0 || K <= 0 || K % 128 || N % 256) return -1;
+    return guarded("mw_mx_gemm", [&]() {
+        MW_HIP(hipSetDevice(device));
+        hipStream_t st = nullptr;  // the null stream: a test entry, nothing to overlap with
+        const size_t na = (size_t)M * K, nw = (size_t)N * K, nc = (size_t)M * N;
+        std::vector<bf16_t> wb(nw);
+        for (size_t i = 0; i < nw; ++i) wb[i] = f32_to_bf16_host(W[i]);
+        DevBuf dA(na * 4), dWb(nw * 2), dA8(na), dW8(nw), dSA(mx_scale_bytes_a(M, K)), dSW(mx_scale_bytes_w(N, K)), dC(nc * 4),
+            dSC(mx_scale_bytes_a(M, N)), dB((size_t)N * 4), dR(nc * 4);
+        MW_HIP(hipMemcpy(dA.p, A, na * 4, hipMemcpyHostToDevice));
+        MW_HIP(hipMemcpy(dWb.p, wb.data(), nw * 2, hipMemcpyHostToDevice));
+        if (bias) MW_HIP(hipMemcpy(dB.p, bias, (size_t)N * 4, hipMemcpyHostToDevice));
+        if (R) MW_HIP(hipMemcpy(dR.p, R, nc * 4, hipMemcpyHostToDevice));
+        launch_quantize_mx_rows(dA.f(), K, M, K, dA8.u8(), K, dSA.u8(), st);
+        launch_quantize_mx_weights(dWb.p, N, K, dW8.u8(), dSW.u8(), st);
+        GemmMxArgs g;
+        g.A = dA8.u8(); g.SA = dSA.u8(); g.lda = K; g.W = dW8.u8(); g.SW = dSW.u8();
+        g.ldw = K; g.C = dC.p; g.ldc = N; g.bias = bias ? dB.f() : nullptr; g.M = M; g.N = N; g.K = K;
+        if (epilogue == MXE_F32_RES) {
+            if (!R) return -1;
+            g.R = dR.f(); g.ldr = N;
+        }
+        if (epilogue == MXE_MX_GELU) g.SC = dSC.u8();
+        launch_gemm_mx(g, epilogue, st);
+        MW_HIP(hipDeviceSynchronize());
+        if (epilogue == MXE_F32_RES) {
+            MW_HIP(hipMemcpy(C_out, dC.p, nc * 4, hipMemcpyDeviceToHost));
+        } else if (epilogue == MXE_BF16) {
+            std::vector<bf16_t> h(nc);
+            MW_HIP(hipMemcpy(h.data(), dC.p, nc * 2, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < nc; ++i) C_out[i] = bf16_to_f32_host(h[i]);
+        } else {
+            std::vector<unsigned char> q(nc), s(mx_scale_bytes_a(M, N));
+            MW_HIP(hipMemcpy(q.data(), dC.p, nc, hipMemcpyDeviceToHost));
+            MW_HIP(hipMemcpy(s.data(), dSC.p, s.size(), hipMemcpyDeviceToHost));
+            decode_rows(q, s, M, N, true, C_out);
+        }
+        if (A_decoded) {
+            std::vector<unsigned char> q(na), s(mx_scale_bytes_a(M, K));
+            MW_HIP(hipMemcpy(q.data(), dA8.p, na, hipMemcpyDeviceToHost));
+            MW_HIP(hipMemcpy(s.data(), dSA.p, s.size(), hipMemcpyDeviceToHost));
+            decode_rows(q, s, M, K, true, A_decoded);
+        }
+        if (W_decoded) {
+            std::vector<unsigned char> q(nw), s(mx_scale_bytes_w(N, K));
+            MW_HIP(hipMemcpy(q.data(), dW8.p, nw, hipMemcpyDeviceToHost));
+            MW_HIP(hipMemcpy(s.data(), dSW.p, s.size(), hipMemcpyDeviceToHost));
+            decode_rows(q, s, N, K, false, W_decoded);
+        }
+        return 0;
+    });
+}
+int mw_mx_layernorm(int device, const float *x, const float *w, const float *b, int rows, int d, float *out_decoded, float *out_bf16) {
+    if (!x || !w || !b || !out_decoded || rows <= 0 || d <= 0 || d % 256 || d > 2048) return -1;
+    return guarded("mw_mx_layernorm", [&]() {
+        MW_HIP(hipSetDevice(device));
+        hipStream_t st = nullptr;
+        const size_t n = (size_t)rows * d;
+        DevBuf dx(n * 4), dw((size_t)d * 4), db((size_t)d * 4), dq(n), ds(mx_scale_bytes_a(rows, d)), dh(n * 2);
+        MW_HIP(hipMemcpy(dx.p, x, n * 4, hipMemcpyHostToDevice));
+        MW_HIP(hipMemcpy(dw.p, w, (size_t)d * 4, hipMemcpyHostToDevice));
+        MW_HIP(hipMemcpy(db.p, b, (size_t)d * 4, hipMemcpyHostToDevice));
+        launch_layernorm_mx(dx.f(), d, dw.f(), db.f(), out_bf16 ? dh.p : nullptr, d, dq.u8(), d,
+                            ds.u8(), rows, d, st);
+        MW_HIP(hipDeviceSynchronize());
+        std::vector<unsigned char> q(n), s(mx_scale_bytes_a(rows, d));
+        MW_HIP(hipMemcpy(q.data(), dq.p, n, hipMemcpyDeviceToHost));
+        MW_HIP(hipMemcpy(s.data(), ds.p, s.size(), hipMemcpyDeviceToHost));
+        decode_rows(q, s, rows, d, true, out_decoded);
+        if (out_bf16) {
+            std::vector<bf16_t> h(n);
+            MW_HIP(hipMemcpy(h.data(), dh.p, n * 2, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < n; ++i) out_bf16[i] = bf16_to_f32_host(h[i]);
+        }
+        return 0;
+    });
+}
+
 int mw_bench_mel(struct whisper_context *ctx, int n_samples, int iters, float *ms_per_call) {
     if (!ctx || !ctx->c || n_samples <= 0 || iters <= 0 || !ms_per_call) return -1;
     return guarded("mw_bench_mel", [&]() {

@@ -31,10 +31,48 @@ const char *const k_non_speech[] = {
 
 }  // namespace
 
+// MX-fp8 encoder workspace for M rows of width d: the LayerNorm rows as e4m3 [M][d] | their block scales | the block scales
+// of fc1's output (K = 4 d); fc1's e4m3 rows themselves reuse the bf16 fc1 buffer.  Each part 256-byte aligned.
+struct MxWorkspace {
+    unsigned char *h8, *hs, *ffs;
+};
+static size_t mx_align(size_t n) { return (n + 255) & ~(size_t)255; }
+static size_t mx_workspace_bytes(int M, int d) {
+    return mx_align((size_t)M * d) + mx_align(mx_scale_bytes_a(M, d)) + mx_align(mx_scale_bytes_a(M, 4 * d));
+}
+static MxWorkspace mx_workspace(unsigned char *base, int M_alloc, int d) {
+    MxWorkspace w;
+    w.h8 = base;
+    w.hs = w.h8 + mx_align((size_t)M_alloc * d);
+    w.ffs = w.hs + mx_align(mx_scale_bytes_a(M_alloc, d));
+    return w;
+}
+// One encoder block's MX-fp8 products (Model::enc_mx) over M rows: x -> LayerNorm (e4m3 + bf16 for V) -> Q|K; and
+// LayerNorm -> fc1 + GELU (e4m3) -> fc2 + residual.  The bf16 path's launches of V, attention and the attention output sit
+// between the two (the callers).
+static void mx_ln_qk(const EncLayer &e, const float *x, void *h_bf16, void *qk, const MxWorkspace &w, int M, int d, hipStream_t s) {
+    launch_layernorm_mx(x, d, e.ln1_w, e.ln1_b, h_bf16, d, w.h8, d, w.hs, M, d, s);
+    GemmMxArgs g;
+    g.A = w.h8; g.SA = w.hs; g.lda = d; g.W = e.qk_w8; g.SW = e.qk_s8; g.ldw = d; g.C = qk; g.ldc = 2 * d; g.bias = e.qk_b;
+    g.M = M; g.N = 2 * d; g.K = d;
+    launch_gemm_mx(g, MXE_BF16, s);
+}
+static void mx_mlp(const EncLayer &e, float *x, void *ff, const MxWorkspace &w, int M, int d, hipStream_t s) {
+    launch_layernorm_mx(x, d, e.ln2_w, e.ln2_b, nullptr, d, w.h8, d, w.hs, M, d, s);
+    GemmMxArgs g;
+    g.A = w.h8; g.SA = w.hs; g.lda = d; g.W = e.fc1_w8; g.SW = e.fc1_s8; g.ldw = d; g.C = ff; g.ldc = 4 * d; g.SC = w.ffs; g.bias = e.fc1_b;
+    g.M = M; g.N = 4 * d; g.K = d;
+    launch_gemm_mx(g, MXE_MX_GELU, s);
+    GemmMxArgs f;
+    f.A = (const unsigned char *)ff; f.SA = w.ffs; f.lda = 4 * d; f.W = e.fc2_w8; f.SW = e.fc2_s8; f.ldw = 4 * d; f.C = x; f.ldc = d;
+    f.bias = e.fc2_b; f.R = x; f.ldr = d; f.M = M; f.N = d; f.K = 4 * d;
+    launch_gemm_mx(f, MXE_F32_RES, s);
+}
+
 Context::~Context() {
     (void)hipSetDevice(device);
     void *ptrs[] = {d_pcm, d_mel_raw, d_mel, d_gmax, d_conv_in, d_x1, d_h, d_qk, d_vt, d_p, d_att, d_ff, d_enc_out, d_x,
-                    d_s, d_cross, d_kself, d_vself, d_kv_idx[0], d_kv_idx[1], d_tokens, d_xd, d_q,
+                    d_s, d_mx, d_cross, d_kself, d_vself, d_kv_idx[0], d_kv_idx[1], d_tokens, d_xd, d_q,
                     d_attd, d_ffd, d_part, d_logits, d_work, d_suppress, d_row_state, d_row_res, d_head_cnt};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -50,10 +88,10 @@ Context::~Context() {
 
 namespace {
 std::unique_ptr<Context> create_context_impl(const unsigned char *data, size_t size, int device, DType wt, const Context *share,
-                                             bool fp8 = false);
+                                             int fp8 = 0);
 }
 
-std::unique_ptr<Context> create_context(const unsigned char *data, size_t size, int device, DType wt, bool fp8) {
+std::unique_ptr<Context> create_context(const unsigned char *data, size_t size, int device, DType wt, int fp8) {
     return create_context_impl(data, size, device, wt, nullptr, fp8);
 }
 
@@ -65,7 +103,7 @@ std::unique_ptr<Context> create_shared_context(const Context &src) {
 
 namespace {
 std::unique_ptr<Context> create_context_impl(const unsigned char *data, size_t size, int device, DType wt, const Context *share,
-                                             bool fp8) {
+                                             int fp8) {
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
         throw std::runtime_error("no HIP device available: this engine has no CPU path");
@@ -97,6 +135,7 @@ std::unique_ptr<Context> create_context_impl(const unsigned char *data, size_t s
     dev_alloc_bytes(c->d_att, T * d * ws);
     dev_alloc_bytes(c->d_ff, T * 4 * d * ws);
     dev_alloc_bytes(c->d_enc_out, T * d * ws);
+    if (c->model.enc_mx) dev_alloc(c->d_mx, mx_workspace_bytes((int)T, (int)d));
     dev_alloc_bytes(c->d_cross, L * 2 * T * d * ws);
     MW_HIP(hipMemsetAsync(c->d_x1, 0, (2 * T + 1) * d * ws, c->st));  // row 0 is the conv2 left zero pad
     MW_HIP(hipMemsetAsync(c->d_vt, 0, d * c->tp * ws, c->st));        // pad columns stay zero
@@ -181,7 +220,7 @@ Hub::~Hub() {
         if (ln.st) (void)hipStreamDestroy(ln.st);
     }
     for (EncLane &el : enc_lanes) {
-        void *ptrs[] = {el.e_conv_in, el.e_x1, el.e_h, el.e_qk, el.e_vt, el.e_att, el.e_ff, el.e_x};
+        void *ptrs[] = {el.e_conv_in, el.e_x1, el.e_h, el.e_qk, el.e_vt, el.e_att, el.e_ff, el.e_x, el.e_mx};
         for (void *p : ptrs)
             if (p) (void)hipFree(p);
         if (el.st) (void)hipStreamDestroy(el.st);
@@ -234,6 +273,7 @@ std::shared_ptr<Hub> create_hub(const Model &m, int device, bool use_graphs) {
         dev_alloc_bytes(el.e_vt, W * da * tp * 2);
         dev_alloc_bytes(el.e_att, W * T * da * 2);
         dev_alloc_bytes(el.e_ff, W * T * 4 * da * 2);
+        if (m.enc_mx) dev_alloc(el.e_mx, mx_workspace_bytes((int)(W * T), (int)da));
         MW_HIP(hipMemsetAsync(el.e_x1, 0, W * (2 * T + 1) * da * 2, el.st));  // row 0 of every window is conv2's left zero pad
         MW_HIP(hipMemsetAsync(el.e_vt, 0, W * da * tp * 2, el.st));           // pad columns stay zero
         MW_HIP(hipStreamSynchronize(el.st));
@@ -347,10 +387,13 @@ void Hub::run_encode(EncLane &ln, const std::vector<EncRequest *> &batch) {
         launch_gemm(g, wt, DType::F32, s);
     }
     const int M = W * n_ctx;
+    const MxWorkspace mxw = mx_workspace(ln.e_mx, ENC_MAX_WINDOWS * hp.n_audio_ctx, d);
     for (int l = 0; l < hp.n_audio_layer; ++l) {
         const EncLayer &e = m.enc[l];
-        launch_layernorm(e_x, d, e.ln1_w, e.ln1_b, e_h, d, wt, M, d, s);
-        {
+        if (m.enc_mx) {
+            mx_ln_qk(e, e_x, e_h, e_qk, mxw, M, d, s);
+        } else {
+            launch_layernorm(e_x, d, e.ln1_w, e.ln1_b, e_h, d, wt, M, d, s);
             GemmArgs g;  // Q | K of all windows
             g.A = e_h; g.lda = d; g.W = e.qk_w; g.ldw = d; g.C = e_qk; g.ldc = 2 * d; g.bias = e.qk_b;
             g.M = M; g.N = 2 * d; g.K = d;
@@ -369,6 +412,10 @@ void Hub::run_encode(EncLane &ln, const std::vector<EncRequest *> &batch) {
             g.A = e_att; g.lda = d; g.W = e.out_w; g.ldw = d; g.C = e_x; g.ldc = d; g.bias = e.out_b;
             g.R = e_x; g.ldr = d; g.M = M; g.N = d; g.K = d;
             launch_gemm(g, wt, DType::F32, s);
+        }
+        if (m.enc_mx) {
+            mx_mlp(e, e_x, e_ff, mxw, M, d, s);
+            continue;
         }
         launch_layernorm(e_x, d, e.ln2_w, e.ln2_b, e_h, d, wt, M, d, s);
         {
@@ -801,10 +848,13 @@ void encode(Context &c, int seek) {
         g.R = m.enc_pe; g.ldr = d;
         gemm(g, wt, DType::F32, st);
     }
+    const MxWorkspace mxw = mx_workspace(c.d_mx, hp.n_audio_ctx, d);
     for (int l = 0; l < hp.n_audio_layer; ++l) {
         const EncLayer &e = m.enc[l];
-        launch_layernorm(c.d_x, d, e.ln1_w, e.ln1_b, c.d_h, d, wt, n_ctx, d, st);
-        {
+        if (m.enc_mx) {
+            mx_ln_qk(e, c.d_x, c.d_h, c.d_qk, mxw, n_ctx, d, st);
+        } else {
+            launch_layernorm(c.d_x, d, e.ln1_w, e.ln1_b, c.d_h, d, wt, n_ctx, d, st);
             GemmArgs g;  // Q | K
             g.A = c.d_h; g.lda = d; g.W = e.qk_w; g.ldw = d; g.C = c.d_qk; g.ldc = 2 * d; g.bias = e.qk_b;
             g.M = n_ctx; g.N = 2 * d; g.K = d;
@@ -840,6 +890,10 @@ void encode(Context &c, int seek) {
             g.A = c.d_att; g.lda = d; g.W = e.out_w; g.ldw = d; g.C = c.d_x; g.ldc = d; g.bias = e.out_b;
             g.R = c.d_x; g.ldr = d; g.M = n_ctx; g.N = d; g.K = d;
             gemm(g, wt, DType::F32, st);
+        }
+        if (m.enc_mx) {
+            mx_mlp(e, c.d_x, c.d_ff, mxw, n_ctx, d, st);
+            continue;
         }
         launch_layernorm(c.d_x, d, e.ln2_w, e.ln2_b, c.d_h, d, wt, n_ctx, d, st);
         {

@@ -133,6 +133,7 @@ struct Hub {
         hipStream_t st = nullptr;
         void *e_conv_in = nullptr, *e_x1 = nullptr, *e_h = nullptr, *e_qk = nullptr, *e_vt = nullptr, *e_att = nullptr, *e_ff = nullptr;
         float *e_x = nullptr;
+        unsigned char *e_mx = nullptr;  // MX-fp8 mode: LayerNorm rows as e4m3 | their block scales | the block scales of fc1's output
         bool busy = false;
     };
     EncLane enc_lanes[N_ENC_LANES];
@@ -165,6 +166,7 @@ struct Context {
     void *d_conv_in = nullptr, *d_x1 = nullptr, *d_h = nullptr, *d_qk = nullptr, *d_vt = nullptr, *d_p = nullptr,
          *d_att = nullptr, *d_ff = nullptr, *d_enc_out = nullptr;
     float *d_x = nullptr, *d_s = nullptr;
+    unsigned char *d_mx = nullptr;  // MX-fp8 mode (Model::enc_mx): as Hub::EncLane::e_mx, for one window
     void *d_cross = nullptr;  // [L][2][n_audio_ctx][d]
     // ---- decoder workspace ----
     void *d_kself = nullptr, *d_vself = nullptr;  // [L][KV_SLOTS][n_text_ctx][d]
@@ -228,7 +230,7 @@ struct Context {
 };
 
 // throws on failure
-std::unique_ptr<Context> create_context(const unsigned char *data, size_t size, int device, DType wt, bool fp8 = false);
+std::unique_ptr<Context> create_context(const unsigned char *data, size_t size, int device, DType wt, int fp8 = 0);
 // another stream context on src's GPU that shares src's uploaded weights (throws on failure)
 std::unique_ptr<Context> create_shared_context(const Context &src);
 

@@ -807,8 +807,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_256_kernel(GemmArgs a) {
     }
 }
 
+}  // namespace
+
 // 16 zero bytes in device memory: what the vector epilogue reads when a GEMM has no bias (an unconditional load)
+namespace {
 __device__ __attribute__((aligned(16))) float g_epi_zero[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+}  // namespace
 const float *epi_zero_device() {
     thread_local const float *ptr[64] = {};
     int dev = 0;
@@ -818,7 +822,6 @@ const float *epi_zero_device() {
     return ptr[dev];
 }
 
-}  // namespace
 
 void launch_gemm(const GemmArgs &args, DType in, DType out, hipStream_t st) {
     GemmArgs a = args;

@@ -76,6 +76,47 @@ struct GemmArgs {
 void launch_gemm(const GemmArgs &a, DType in, DType out, hipStream_t st);
 
 // ------------------------------------------------------------------------------------------
+// MX-fp8 encoder GEMMs (gemm_mx.hip; MW_PRECISION_FP8_MX): OCP e4m3 elements with one E8M0 scale (2^(s - 127)) per block of
+// 32 consecutive k, multiplied by v_mfma_scale_f32_16x16x128_f8f6f4.
+//   scale(block) = the smallest power of two with absmax / scale <= 448;  element = RNE(value / scale)  (never saturates)
+// Elements are plain row-major bytes [rows][K].  Scales are stored in the order the kernel's lanes consume them (one
+// 8-byte / 4-byte record per lane and k-step of 128): see mx_sa_off / mx_sw_off.
+// ------------------------------------------------------------------------------------------
+// activations [M][K]: record = the 8 row tiles (16 rows each) of a 128-row block for one (row & 15, k-block & 3)
+__host__ __device__ inline size_t mx_sa_off(int m, int kb, int MB) {
+    return (((size_t)(kb >> 2) * MB + (m >> 7)) * 64 + ((kb & 3) * 16 + (m & 15))) * 8 + ((m >> 4) & 7);
+}
+// weights [N][K]: record = the 4 row tiles of a 64-row block
+__host__ __device__ inline size_t mx_sw_off(int n, int kb, int NB) {
+    return (((size_t)(kb >> 2) * NB + (n >> 6)) * 64 + ((kb & 3) * 16 + (n & 15))) * 4 + ((n >> 4) & 3);
+}
+inline int mx_row_blocks_a(int M) { return 2 * ((M + 255) / 256); }                       // 128-row blocks, padded to whole 256-row tiles
+inline size_t mx_scale_bytes_a(int M, int K) { return (size_t)(K / 128) * mx_row_blocks_a(M) * 512; }
+inline size_t mx_scale_bytes_w(int N, int K) { return (size_t)(K / 128) * (N / 64) * 256; }
+// bf16 [N][K] (row stride K) -> e4m3 bytes + scales in weight order; K % 128 == 0, N % 64 == 0
+void launch_quantize_mx_weights(const void *w_bf16, int N, int K, unsigned char *q, unsigned char *s, hipStream_t st);
+// fp32 [M][K] -> e4m3 bytes + scales in activation order (parity entry point; the encoder's producers quantise in place)
+void launch_quantize_mx_rows(const float *x, long ldx, int M, int K, unsigned char *q, long ldq, unsigned char *s, hipStream_t st);
+// LayerNorm (ggml_norm, as launch_layernorm) whose result leaves as MX-fp8 (q, s) and, when out_bf16 is given, as bf16 too
+void launch_layernorm_mx(const float *x, long ldx, const float *w, const float *b, void *out_bf16, long ldo, unsigned char *q,
+                         long ldq, unsigned char *s, int rows, int d, hipStream_t st);
+enum { MXE_BF16 = 0, MXE_F32_RES = 1, MXE_MX_GELU = 2 };
+struct GemmMxArgs {
+    const unsigned char *A = nullptr, *SA = nullptr;  // [M][K] e4m3, scales in activation order
+    const unsigned char *W = nullptr, *SW = nullptr;  // [N][K] e4m3, scales in weight order
+    void *C = nullptr;               // MXE_BF16: bf16 [M][N]; MXE_F32_RES: fp32 [M][N] (+= R); MXE_MX_GELU: e4m3 [M][N]
+    unsigned char *SC = nullptr;     // MXE_MX_GELU: the output's scales, activation order for K' = N
+    const float *bias = nullptr, *R = nullptr;
+    long lda = 0, ldw = 0, ldc = 0, ldr = 0;
+    int M = 0, N = 0, K = 0;
+    float alpha = 1.0f;
+    const float *epi_zero = nullptr;  // set by the launcher
+};
+// C = epilogue(alpha * A W^T + bias): 256 x 256 persistent tiles, K % 128 == 0, N % 256 == 0
+void launch_gemm_mx(const GemmMxArgs &a, int epi, hipStream_t st);
+const float *epi_zero_device();  // gemm.hip: 16 zero bytes on the current device
+
+// ------------------------------------------------------------------------------------------
 // K3 LayerNorm, softmax, misc (enc_misc.hip)
 // ------------------------------------------------------------------------------------------
 void launch_layernorm(const float *x, long ldx, const float *w, const float *b, void *out, long ldo, DType out_t,

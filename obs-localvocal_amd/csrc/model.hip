@@ -227,6 +227,12 @@ struct Loader {
         hipLaunchKernelGGL(quantize_rows_fp8_kernel, dim3((unsigned)N), dim3(256), 0, st, (bf16_t *)w_bf16, w8, scale, (int)K);
         MW_HIP(hipGetLastError());
     }
+    // MX-fp8 copy (e4m3 bytes + block scales in the GEMM's lane order) of an uploaded bf16 matrix [N][K]; the bf16 copy stays
+    void quantize_mx(const void *w_bf16, size_t N, size_t K, unsigned char *&w8, unsigned char *&s8) {
+        w8 = (unsigned char *)alloc(N * K);
+        s8 = (unsigned char *)alloc(mx_scale_bytes_w((int)N, (int)K));
+        launch_quantize_mx_weights(w_bf16, (int)N, (int)K, w8, s8, st);
+    }
     float *vec(const std::string &name, size_t n) {
         float *p = (float *)alloc(n * 4);
         put(name, n, p, DType::F32);
@@ -325,7 +331,7 @@ void free_device_block(void *p) {
 }
 }  // namespace
 
-void load_model(Model &m, const unsigned char *data, size_t size, DType wt, hipStream_t st, bool fp8) {
+void load_model(Model &m, const unsigned char *data, size_t size, DType wt, hipStream_t st, int fp8) {
     if (fp8 && wt != DType::BF16) throw std::runtime_error("fp8 weights go with bf16 activations");
     Cursor c{data, data + size};
     if (c.rd<uint32_t>() != GGML_MAGIC) throw std::runtime_error("bad magic (not a ggml model file)");
@@ -417,7 +423,11 @@ void load_model(Model &m, const unsigned char *data, size_t size, DType wt, hipS
     if (fp8)  // e4m3 copies + row scales of the decoder projections and the logits matrix: per layer Wq|Wk|Wv (3 d^2), the two
               // attention outputs and cross-q (3 d^2), fc1 and fc2 (8 d^2) = 14 d^2 bytes and 3 + 3 + 4 + 1 = 11 d scales
         m.arena_size += Ld * 14 * d * d + (size_t)hp.n_vocab * d + (Ld * 11 * d + hp.n_vocab) * 4 + (4 + 12 * Ld) * 256;
-    m.dec_fp8 = fp8;
+    m.dec_fp8 = fp8 != 0;
+    m.enc_mx = fp8 >= 2;
+    if (m.enc_mx && d % 256 != 0) throw std::runtime_error("MX-fp8 encoder: n_audio_state must be a multiple of 256");
+    if (m.enc_mx)  // Q|K (2 d^2), fc1 and fc2 (8 d^2) as bytes + one scale byte per 32
+        m.arena_size += Le * (10 * d * d + 10 * d * d / 32 + 6 * 256);
     MW_HIP(hipMalloc((void **)&m.arena, m.arena_size));
     m.arena_owner = std::shared_ptr<void>(m.arena, free_device_block);
     L.staging_size = max_bytes;
@@ -449,6 +459,11 @@ void load_model(Model &m, const unsigned char *data, size_t size, DType wt, hipS
             e.fc1_b = L.vec(p + "mlp.0.bias", 4 * d);
             e.fc2_w = L.mat(p + "mlp.2.weight", 4 * d * d);
             e.fc2_b = L.vec(p + "mlp.2.bias", d);
+            if (m.enc_mx) {
+                L.quantize_mx(e.qk_w, 2 * d, d, e.qk_w8, e.qk_s8);
+                L.quantize_mx(e.fc1_w, 4 * d, d, e.fc1_w8, e.fc1_s8);
+                L.quantize_mx(e.fc2_w, d, 4 * d, e.fc2_w8, e.fc2_s8);
+            }
         }
         m.ln_post_w = L.vec("encoder.ln_post.weight", d);
         m.ln_post_b = L.vec("encoder.ln_post.bias", d);

@@ -51,6 +51,9 @@ struct EncLayer {
     float *fc1_b;
     void *fc2_w;
     float *fc2_b;
+    // MX-fp8 mode (Model::enc_mx): Q|K, fc1 and fc2 again as e4m3 bytes + E8M0 block scales in the order the MX GEMM's lanes
+    // read them (kernels.hpp, mx_sw_off)
+    unsigned char *qk_w8 = nullptr, *qk_s8 = nullptr, *fc1_w8 = nullptr, *fc1_s8 = nullptr, *fc2_w8 = nullptr, *fc2_s8 = nullptr;
 };
 
 struct DecLayer {
@@ -99,6 +102,10 @@ struct Model {
     // the scale is a power of two — so prompt prefill (bf16 kernels) and the steps compute with one and the same model.
     // The encoder keeps bf16 weights (its GEMMs are not bound by weight bytes).
     bool dec_fp8 = false;
+    // MW_PRECISION_FP8_MX: additionally the encoder's Q|K, fc1 and fc2 products run in MX-fp8 (gemm_mx.hip): e4m3 weights
+    // AND activations with one power-of-two scale per block of 32 along k, on v_mfma_scale_f32_16x16x128_f8f6f4.  The
+    // bf16 copies are kept (V, attention output, conv stem and cross K / V stay bf16).  Needs n_audio_state % 256 == 0.
+    bool enc_mx = false;
     unsigned char *tok_emb8 = nullptr;
     float *tok_emb_s = nullptr;
     // device arena
@@ -114,7 +121,8 @@ struct Model {
 
 // Parses `size` bytes at `data` (a whole ggml-*.bin image) and uploads to the current HIP device.
 // Throws std::runtime_error on malformed input.
-// fp8 = true (with wt = BF16): additionally quantise the decoder's matrices to e4m3 (Model::dec_fp8).
-void load_model(Model &m, const unsigned char *data, size_t size, DType wt, hipStream_t st, bool fp8 = false);
+// fp8 (with wt = BF16): 1 = additionally quantise the decoder's matrices to e4m3 (Model::dec_fp8); 2 = that and the
+// encoder's MX-fp8 weights (Model::enc_mx).
+void load_model(Model &m, const unsigned char *data, size_t size, DType wt, hipStream_t st, int fp8 = 0);
 
 }  // namespace mw

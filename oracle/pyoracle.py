@@ -68,6 +68,8 @@ def lib():
         L.ow_decode.argtypes = [P, C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int]
         L.ow_logits.restype = C.POINTER(C.c_float); L.ow_logits.argtypes = [P]
         FP = C.POINTER(C.c_float)
+        L.ow_set_mx_encoder.argtypes = [P, C.c_int]; L.ow_set_mx_encoder.restype = None
+        L.ow_mx_qdq.argtypes = [FP, C.c_int, C.c_int]; L.ow_mx_qdq.restype = None
         L.ow_process_logits.argtypes = [P, C.POINTER(OwParams), C.c_float, FP, C.POINTER(C.c_int32), C.c_int,
                                         C.c_int, C.c_int, FP, FP, FP]
         L.ow_full.argtypes = [P, C.POINTER(OwParams), FP, C.c_int]
@@ -141,6 +143,10 @@ class Oracle:
         n_len = self.L.ow_mel_n_len(self.ctx)
         return np.ctypeslib.as_array(self.L.ow_mel_data(self.ctx), (self.n_mels, n_len)).copy()
 
+    def set_mx_encoder(self, on: bool = True) -> None:
+        """the MX-fp8 twin of the engine's PRECISION_FP8_MX encoder (whisper_oracle.cpp: mx_qdq_rows)"""
+        self.L.ow_set_mx_encoder(self.ctx, 1 if on else 0)
+
     def encode(self, seek: int = 0, audio_ctx: int = 0) -> np.ndarray:
         self.L.ow_encode(self.ctx, seek, audio_ctx)
         n_ctx = audio_ctx if audio_ctx > 0 else self.n_audio_ctx
@@ -190,3 +196,12 @@ class Oracle:
         probs = np.zeros(100, np.float32)
         lid = self.L.ow_lang_auto_detect(self.ctx, offset_ms, _fp(probs))
         return lid, probs
+
+
+def mx_qdq(a: np.ndarray) -> np.ndarray:
+    """MX-fp8 quantise + dequantise of the rows of a 2-D array (blocks of 32 along the last axis): the oracle's statement of
+    the rule the engine's MX-fp8 kernels implement."""
+    out = np.ascontiguousarray(a, dtype=np.float32).copy()
+    assert out.ndim == 2 and out.shape[1] % 32 == 0
+    lib().ow_mx_qdq(_fp(out), out.shape[0], out.shape[1])
+    return out

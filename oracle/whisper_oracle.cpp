@@ -189,6 +189,39 @@ void layer_norm(float *out, const float *x, const float *w, const float *b, int 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// OCP microscaling fp8 (MX-fp8, e4m3 elements, one power-of-two scale per block of 32), quantise + dequantise.
+// No counterpart in whisper.cpp: this is the arithmetic the engine's MW_PRECISION_FP8_MX mode declares
+// (obs-localvocal_amd/csrc/gemm_mx.hip), restated so that the mode can be tested against the same numbers.
+//   scale = the smallest power of two s with absmax(block) / s <= 448 (clamped at 2^-127);
+//   element = the e4m3 value nearest to value / s, ties to even (subnormals 2^-9 .. 7 x 2^-9 included).
+// ---------------------------------------------------------------------------------------------
+inline float e4m3_nearest(float x) {  // |x| <= 448
+    const float a = fabsf(x);
+    if (a == 0.0f) return x;
+    int e;
+    (void)frexpf(a, &e);                 // a = f x 2^e, f in [0.5, 1): binade 2^(e-1)
+    const int q = std::max(e - 1, -6);   // subnormals share the spacing of the lowest binade
+    const float step = ldexpf(1.0f, q - 3);
+    return copysignf(nearbyintf(a / step) * step, x);  // default rounding mode: to nearest, ties to even
+}
+void mx_qdq_rows(float *a, size_t rows, int K, size_t ld) {
+#pragma omp parallel for schedule(static)
+    for (long r = 0; r < (long)rows; ++r)
+        for (int k0 = 0; k0 < K; k0 += 32) {
+            float *b = a + (size_t)r * ld + k0;
+            float amax = 0.0f;
+            for (int i = 0; i < 32; ++i) amax = std::max(amax, fabsf(b[i]));
+            if (amax == 0.0f) continue;
+            int e;
+            (void)frexpf(amax / 448.0f, &e);                // amax / 448 = f x 2^e, f in [0.5, 1)
+            if (ldexpf(448.0f, e - 1) >= amax) e -= 1;      // exactly a power of two times 448: the smaller scale is enough
+            e = std::max(e, -127);
+            const float s = ldexpf(1.0f, e), inv = ldexpf(1.0f, -e);
+            for (int i = 0; i < 32; ++i) b[i] = e4m3_nearest(b[i] * inv) * s;
+        }
+}
+
 inline float gelu_tanh(float x) {
     // ggml_gelu: 0.5*x*(1 + tanh(sqrt(2/pi)*x*(1 + 0.044715*x*x)))   (A.3)
     const float c = 0.79788456080286535587989211986876f, a = 0.044715f;
@@ -214,6 +247,10 @@ struct ow_context {
     int lang_id = 0;
     int n_decode_calls = 0, n_encode_calls = 0;
     std::string tmp_str;
+    // MX-fp8 twin of the engine's MW_PRECISION_FP8_MX encoder (ow_set_mx_encoder): the operands of the Q, K, fc1 and fc2
+    // products of every encoder block pass through mx_qdq_rows first (weights once, cached here)
+    bool mx_encoder = false;
+    std::map<std::string, std::vector<float>> mx_weights;
 };
 
 namespace {
@@ -518,15 +555,31 @@ void encode(ow_context &c, int mel_offset) {
         }
         for (int t = 0; t < n_ctx; ++t) x[(size_t)t * d + co] = gelu_tanh(acc[t]) + pe[(size_t)t * d + co];
     }
+    std::vector<float> hmx;
     std::vector<float> h((size_t)n_ctx * d), q((size_t)n_ctx * d), k((size_t)n_ctx * d), v((size_t)n_ctx * d),
         att((size_t)n_ctx * d), tmp((size_t)n_ctx * d), ff((size_t)n_ctx * 4 * d);
     const float kq_scale = 1.0f / sqrtf((float)dh);
     for (int l = 0; l < hp.n_audio_layer; ++l) {
         const std::string p = "encoder.blocks." + std::to_string(l) + ".";
         layer_norm(h.data(), x.data(), m.get(p + "attn_ln.weight").data(), m.get(p + "attn_ln.bias").data(), n_ctx, d);
-        matmul_nt(q.data(), d, h.data(), d, m.get(p + "attn.query.weight").data(), d, m.get(p + "attn.query.bias").data(),
-                  n_ctx, d, d);
-        matmul_nt(k.data(), d, h.data(), d, m.get(p + "attn.key.weight").data(), d, nullptr, n_ctx, d, d);
+        // MX twin: weights and the activation operand of the Q, K, fc1, fc2 products on the MX-fp8 grid; V reads h as it is
+        auto mxw = [&](const std::string &name, int K) -> const float * {
+            if (!c.mx_encoder) return m.get(name).data();
+            auto it = c.mx_weights.find(name);
+            if (it == c.mx_weights.end()) {
+                it = c.mx_weights.emplace(name, m.get(name)).first;
+                mx_qdq_rows(it->second.data(), it->second.size() / K, K, K);
+            }
+            return it->second.data();
+        };
+        const float *hq = h.data();
+        if (c.mx_encoder) {
+            hmx = h;
+            mx_qdq_rows(hmx.data(), n_ctx, d, d);
+            hq = hmx.data();
+        }
+        matmul_nt(q.data(), d, hq, d, mxw(p + "attn.query.weight", d), d, m.get(p + "attn.query.bias").data(), n_ctx, d, d);
+        matmul_nt(k.data(), d, hq, d, mxw(p + "attn.key.weight", d), d, nullptr, n_ctx, d, d);
         matmul_nt(v.data(), d, h.data(), d, m.get(p + "attn.value.weight").data(), d, m.get(p + "attn.value.bias").data(),
                   n_ctx, d, d);
 #pragma omp parallel
@@ -561,11 +614,12 @@ void encode(ow_context &c, int mel_offset) {
                   n_ctx, d, d);
         for (size_t i = 0; i < x.size(); ++i) x[i] += tmp[i];
         layer_norm(h.data(), x.data(), m.get(p + "mlp_ln.weight").data(), m.get(p + "mlp_ln.bias").data(), n_ctx, d);
-        matmul_nt(ff.data(), 4 * d, h.data(), d, m.get(p + "mlp.0.weight").data(), d, m.get(p + "mlp.0.bias").data(),
-                  n_ctx, 4 * d, d);
+        if (c.mx_encoder) mx_qdq_rows(h.data(), n_ctx, d, d);
+        matmul_nt(ff.data(), 4 * d, h.data(), d, mxw(p + "mlp.0.weight", d), d, m.get(p + "mlp.0.bias").data(), n_ctx, 4 * d, d);
         for (auto &f : ff) f = gelu_tanh(f);
-        matmul_nt(tmp.data(), d, ff.data(), 4 * d, m.get(p + "mlp.2.weight").data(), 4 * d,
-                  m.get(p + "mlp.2.bias").data(), n_ctx, d, 4 * d);
+        if (c.mx_encoder) mx_qdq_rows(ff.data(), n_ctx, 4 * d, 4 * (size_t)d);
+        matmul_nt(tmp.data(), d, ff.data(), 4 * d, mxw(p + "mlp.2.weight", 4 * d), 4 * d, m.get(p + "mlp.2.bias").data(), n_ctx, d,
+                  4 * d);
         for (size_t i = 0; i < x.size(); ++i) x[i] += tmp[i];
     }
     c.enc_out.resize((size_t)n_ctx * d);
@@ -1357,6 +1411,8 @@ int ow_pcm_to_mel(ow_context *c, const float *pcm, int n) {
 int ow_mel_n_len(ow_context *c) { return c->mel.n_len; }
 int ow_mel_n_len_org(ow_context *c) { return c->mel.n_len_org; }
 const float *ow_mel_data(ow_context *c) { return c->mel.data.data(); }
+void ow_set_mx_encoder(ow_context *c, int on) { c->mx_encoder = on != 0; }
+void ow_mx_qdq(float *a, int rows, int K) { mx_qdq_rows(a, (size_t)rows, K, (size_t)K); }
 int ow_encode(ow_context *c, int seek, int audio_ctx) {
     c->exp_n_audio_ctx = audio_ctx;
     encode(*c, seek);

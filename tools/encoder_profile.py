@@ -38,22 +38,33 @@ def main():
     model = sys.argv[1] if len(sys.argv) > 1 else "large-v3"
     iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
     windows = int(sys.argv[3]) if len(sys.argv) > 3 else 1   # > 1: that many contexts on one upload encode at the same time
+    pname = sys.argv[4] if len(sys.argv) > 4 else "bf16"     # bf16 | fp8 | fp8mx (the encoder's Q|K, fc1, fc2 in MX-fp8)
+    prec = {"bf16": pkg.PRECISION_BF16, "fp8": pkg.PRECISION_FP8, "fp8mx": pkg.PRECISION_FP8_MX}[pname]
     d = os.environ.get("MI355_WHISPER_BENCH_DIR", "/tmp/mi355_whisper_bench")
     os.makedirs(d, exist_ok=True)
     path = os.path.join(d, f"ggml-{model}-synth-s1234.bin")
     if not os.path.exists(path):
         synth_large.write_large(path, model, seed=1234, quiet_special=True)
-    eng = pkg.Engine(path, precision=pkg.PRECISION_BF16)
+    eng = pkg.Engine(path, precision=prec)
     if windows <= 1:
         eng.mel(ggml_io.synth_pcm(100, 30.0))
         ms = C.c_float(0)
         assert eng.L.mw_bench_encode(eng.ctx, iters, C.byref(ms)) == 0
-        print(f"encoder + cross-K/V of one 30 s window ({model}, bf16): {ms.value:.3f} ms per pass ({iters} passes)")
+        print(f"encoder + cross-K/V of one 30 s window ({model}, {pname}): {ms.value:.3f} ms per pass ({iters} passes)")
+        if prec != pkg.PRECISION_BF16 and os.environ.get("ENC_COMPARE"):
+            # what the precision costs: this encoder's output against the bf16 engine's on the same file and audio
+            out = eng.encode(0)
+            ref_eng = pkg.Engine(path, precision=pkg.PRECISION_BF16)
+            ref_eng.mel(ggml_io.synth_pcm(100, 30.0))
+            ref = ref_eng.encode(0)
+            ref_eng.close()
+            print(f"   encoder output vs the bf16 engine: max |d| / max |bf16| = {np.abs(out - ref).max() / np.abs(ref).max():.4f}, "
+                  f"rms |d| / rms = {np.sqrt(np.mean((out - ref) ** 2)) / np.sqrt(np.mean(ref ** 2)):.4f}, finite: {bool(np.isfinite(out).all())}")
     else:
         # the windows of `windows` streams through the hub: their encode calls meet in one pass with M = windows x 1500
         import threading
         import time
-        engs = [eng] + [pkg.Engine(path, precision=pkg.PRECISION_BF16, share=eng) for _ in range(windows - 1)]
+        engs = [eng] + [pkg.Engine(path, precision=prec, share=eng) for _ in range(windows - 1)]
         for i, e in enumerate(engs):
             e.mel(ggml_io.synth_pcm(100 + i, 30.0))
         gate = threading.Barrier(windows)
@@ -72,7 +83,7 @@ def main():
             t.join()
         dt = time.time() - t0
         s1 = eng.hub_stats()
-        print(f"{windows} windows at a time ({model}, bf16): {1000.0 * dt / (iters + 1) / windows:.3f} ms per window, "
+        print(f"{windows} windows at a time ({model}, {pname}): {1000.0 * dt / (iters + 1) / windows:.3f} ms per window, "
               f"{s1[4] - s0[4]} windows in {s1[3] - s0[3]} encoder passes")
         for e in engs[1:]:
             e.close()

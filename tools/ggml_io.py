@@ -383,6 +383,26 @@ def e4m3_quantize_dequantize_rows(a: np.ndarray) -> np.ndarray:
     return (np.sign(y) * q * 2.0 ** e).astype(np.float32)
 
 
+# --------------------------------------------------------------------------------------------
+# MX-fp8 (OCP microscaling: e4m3 elements, one power-of-two scale per block of 32 along k): the format of the encoder
+# products MW_PRECISION_FP8_MX runs on the fp8 matrix cores (obs-localvocal_amd/csrc/gemm_mx.hip)
+# --------------------------------------------------------------------------------------------
+MX_ENCODER_SUFFIXES = (".attn.query.weight", ".attn.key.weight", ".mlp.0.weight", ".mlp.2.weight")
+
+
+def is_mx_encoder_tensor(name: str) -> bool:
+    """The encoder matrices MW_PRECISION_FP8_MX multiplies in MX-fp8: Q, K, fc1, fc2 of every block."""
+    return name.startswith("encoder.blocks.") and name.endswith(MX_ENCODER_SUFFIXES)
+
+
+def mxfp8_quantize_dequantize(a: np.ndarray) -> np.ndarray:
+    """a [..., K] float32, K % 32 == 0 -> the nearest MX-fp8 values: per block of 32 along the last axis the smallest
+    power-of-two scale that brings the block under 448, e4m3 elements rounded to nearest even.  Idempotent; exact in bf16/f16."""
+    a = np.asarray(a, dtype=np.float32)
+    assert a.shape[-1] % 32 == 0
+    return e4m3_quantize_dequantize_rows(a.reshape(-1, 32)).reshape(a.shape)
+
+
 def make_model_file(path: str, preset: str = "micro.en", seed: int = 1234, ftype: int | None = None,
                     quiet_special: bool = False, **overrides) -> HParams:
     hp = HParams(**{**PRESETS[preset].__dict__, **overrides})

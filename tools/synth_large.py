@@ -15,9 +15,10 @@ from tools import ggml_io
 
 
 def write_large(path: str, preset: str = "large-v3", seed: int = 1234, quiet_special: bool = True,
-                fp8_decoder: bool = False) -> ggml_io.HParams:
+                fp8_decoder: bool = False, mx_encoder: bool = False) -> ggml_io.HParams:
     """fp8_decoder: the tensors MW_PRECISION_FP8 quantises are written already rounded to e4m3 x 2^s(row), so that an fp32
-    reader of the file (the oracle) and the engine's fp8 mode hold exactly the same weights."""
+    reader of the file (the oracle) and the engine's fp8 mode hold exactly the same weights.  mx_encoder: likewise the
+    encoder matrices MW_PRECISION_FP8_MX multiplies in MX-fp8 (blocks of 32 along k)."""
     hp = ggml_io.PRESETS[preset]
     rng = np.random.default_rng(seed)
     tmp = path + ".tmp.%d" % os.getpid()
@@ -50,6 +51,8 @@ def write_large(path: str, preset: str = "large-v3", seed: int = 1234, quiet_spe
                 a = rng.standard_normal(n, dtype=np.float32) * np.float32(max(0.02, 1.0 / np.sqrt(fan_in)))
             if fp8_decoder and ggml_io.is_fp8_decoder_tensor(name):
                 a = ggml_io.e4m3_quantize_dequantize_rows(a.reshape(shape[0], -1)).reshape(-1)
+            if mx_encoder and ggml_io.is_mx_encoder_tensor(name):
+                a = ggml_io.mxfp8_quantize_dequantize(a.reshape(shape[0], -1)).reshape(-1)
             use_f16 = hp.ftype == 1 and is_mat
             ne = list(reversed(shape))
             nb = name.encode()
