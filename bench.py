@@ -131,8 +131,10 @@ def run_streams(a, rank, local_rank, world, dist, steps=None, warmup=None, pkg=N
     if not mine:
         raise SystemExit("fewer streams than ranks")
     t0 = time.time()
-    first = pkg.Engine(model_path, precision=pkg.PRECISION_BF16, device=local_rank)
-    engs = [first] + [pkg.Engine(model_path, precision=pkg.PRECISION_BF16, device=local_rank, share=first) for _ in mine[1:]]
+    prec_name = a.precision if a.precision in ("fp8", "fp8mx") and getattr(a, "workload", "single") == "streams" else "bf16"
+    prec = {"bf16": pkg.PRECISION_BF16, "fp8": pkg.PRECISION_FP8, "fp8mx": pkg.PRECISION_FP8_MX}[prec_name]
+    first = pkg.Engine(model_path, precision=prec, device=local_rank)
+    engs = [first] + [pkg.Engine(model_path, precision=prec, device=local_rank, share=first) for _ in mine[1:]]
     t_load = time.time() - t0
     pcms, params = [], []
     for e, sid in zip(engs, mine):
@@ -188,8 +190,8 @@ def run_streams(a, rank, local_rank, world, dist, steps=None, warmup=None, pkg=N
         out = {
             "metric": "audio-sec transcribed/sec", "value": round(audio / elapsed, 2), "unit": "audio-sec/sec", "n_gpus": world,
             "steps": steps, "warmup": warmup, "ms_per_step": round(1000.0 * elapsed / steps, 3), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"whisper {model} bf16, greedy, {a.streams} streams sharded i mod {world} ({len(engs)} on rank 0, one "
+            "scaling": "strong", "vs_baseline": None, "dtype": prec_name, "data": "synthetic",
+            "config": {"workload": f"whisper {model} {prec_name}, greedy, {a.streams} streams sharded i mod {world} ({len(engs)} on rank 0, one "
                                    f"context + worker thread each, one weight upload per GPU), 30 s window per stream per step, "
                                    f"{decode_steps} forced decode steps, synthetic GGML weights (seed 1234)",
                        "streams": a.streams, "concurrency_per_gpu": conc, "decode_steps": decode_steps,
@@ -238,8 +240,9 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--model", default="large-v3")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp8"],
-                    help="fp8: bf16 engine with the decoder's projection / logits matrices streamed as e4m3 (BASELINE configs[4])")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp8", "fp8mx"],
+                    help="fp8: bf16 engine with the decoder's projection / logits matrices streamed as e4m3 (BASELINE configs[4]); "
+                         "fp8mx: that and the encoder's Q|K / fc1 / fc2 products in MX-fp8 on the fp8 matrix cores")
     ap.add_argument("--beam", type=int, default=5)
     ap.add_argument("--decode-steps", type=int, default=128)
     ap.add_argument("--roofline-class", default="cross_attn", choices=sorted(GEMV_CLASSES),
@@ -323,7 +326,7 @@ def main():
 
     torch.cuda.set_device(local_rank)
     t0 = time.time()
-    eng = pkg.Engine(model_path, precision={"bf16": pkg.PRECISION_BF16, "fp32": pkg.PRECISION_FP32, "fp8": pkg.PRECISION_FP8}[a.precision],
+    eng = pkg.Engine(model_path, precision={"bf16": pkg.PRECISION_BF16, "fp32": pkg.PRECISION_FP32, "fp8": pkg.PRECISION_FP8, "fp8mx": pkg.PRECISION_FP8_MX}[a.precision],
                      device=local_rank)
     t_load = time.time() - t0
     eng.set_force_decode_steps(a.decode_steps)
@@ -432,7 +435,7 @@ def main():
             #  (2) eager, each launch bracketed by HIP events on the engine's stream (graphs off): includes the gap of
             #      back-to-back eager launches; reported beside it (`*_eager_events`).  Used for `achieved` only when (1) failed.
             n_l, ms, _nw = prof[k]
-            b_launch = gemv_bytes(k, eng.n_text_state, eng.n_vocab, rows, wbytes, fp8=a.precision == "fp8")
+            b_launch = gemv_bytes(k, eng.n_text_state, eng.n_vocab, rows, wbytes, fp8=a.precision in ("fp8", "fp8mx"))
             eager_us = 1000.0 * ms / max(n_l, 1)
             graph_us = in_graph.get(k) if in_graph.get(k) and in_graph[k] > 0 else None
             used_us = graph_us or eager_us

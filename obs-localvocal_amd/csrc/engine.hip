@@ -57,6 +57,23 @@ static void mx_ln_qk(const EncLayer &e, const float *x, void *h_bf16, void *qk, 
     g.M = M; g.N = 2 * d; g.K = d;
     launch_gemm_mx(g, MXE_BF16, s);
 }
+// ln_post (bf16 rows for the getter + e4m3 rows) and the cross K (scaled by dh^-1/4, no bias) / V (+ bias) of every decoder
+// layer as two batched MX-fp8 launches, into one context's buffers
+static void mx_ln_post_cross(const Model &m, const float *x, void *enc_out_bf16, void *cross, const MxWorkspace &w, int n_ctx, hipStream_t s) {
+    const HParams &hp = m.hp;
+    const int d = hp.n_audio_state, L = hp.n_text_layer;
+    launch_layernorm_mx(x, d, m.ln_post_w, m.ln_post_b, enc_out_bf16, d, w.h8, d, w.hs, n_ctx, d, s);
+    const long sb = (long)mx_scale_bytes_w(d, d);
+    GemmMxArgs g;
+    g.A = w.h8; g.SA = w.hs; g.lda = d; g.W = m.ckv_w8; g.SW = m.ckv_s8; g.ldw = d; g.C = cross; g.ldc = d;
+    g.M = n_ctx; g.N = d; g.K = d; g.nz = L; g.sW = 2L * d * d; g.sSW = 2 * sb; g.sC = 2L * hp.n_audio_ctx * d;
+    g.alpha = powf(64.0f, -0.25f);
+    launch_gemm_mx(g, MXE_BF16, s);
+    GemmMxArgs v = g;
+    v.W = m.ckv_w8 + (size_t)d * d; v.SW = m.ckv_s8 + sb; v.C = (char *)cross + (size_t)hp.n_audio_ctx * d * 2;
+    v.bias = m.ckv_b + d; v.sBias = 2L * d; v.alpha = 1.0f;
+    launch_gemm_mx(v, MXE_BF16, s);
+}
 static void mx_mlp(const EncLayer &e, float *x, void *ff, const MxWorkspace &w, int M, int d, hipStream_t s) {
     launch_layernorm_mx(x, d, e.ln2_w, e.ln2_b, nullptr, d, w.h8, d, w.hs, M, d, s);
     GemmMxArgs g;
@@ -435,6 +452,11 @@ void Hub::run_encode(EncLane &ln, const std::vector<EncRequest *> &batch) {
     const long per_layer = 2L * hp.n_audio_ctx * d;
     for (int w = 0; w < W; ++w) {  // ln_post and the cross K / V of every decoder layer, into the window's own context
         Context &c = *batch[w]->c;
+        if (m.enc_mx) {
+            mx_ln_post_cross(m, e_x + (size_t)w * n_ctx * d, c.d_enc_out, c.d_cross, mxw, n_ctx, s);
+            c.n_ctx_cur = n_ctx;
+            continue;
+        }
         launch_layernorm(e_x + (size_t)w * n_ctx * d, d, m.ln_post_w, m.ln_post_b, c.d_enc_out, d, wt, n_ctx, d, s);
         GemmArgs g;
         g.A = c.d_enc_out; g.lda = d; g.W = m.ckv_w; g.ldw = d; g.C = c.d_cross; g.ldc = d;
@@ -909,8 +931,11 @@ void encode(Context &c, int seek) {
             gemm(g, wt, DType::F32, st);
         }
     }
-    launch_layernorm(c.d_x, d, m.ln_post_w, m.ln_post_b, c.d_enc_out, d, wt, n_ctx, d, st);
-    {   // cross K (scaled by dh^-1/4, no bias) and V (+bias) of every decoder layer, batched over layers
+    if (m.enc_mx) {
+        mx_ln_post_cross(m, c.d_x, c.d_enc_out, c.d_cross, mxw, n_ctx, st);
+    } else {
+        launch_layernorm(c.d_x, d, m.ln_post_w, m.ln_post_b, c.d_enc_out, d, wt, n_ctx, d, st);
+        // cross K (scaled by dh^-1/4, no bias) and V (+bias) of every decoder layer, batched over layers
         const int L = hp.n_text_layer;
         const long per_layer = 2L * hp.n_audio_ctx * d;
         GemmArgs g;

@@ -160,14 +160,17 @@ __global__ __launch_bounds__(512) void gemm_mxfp8_256_kernel(GemmMxArgs a) {
     const int wr = wave >> 2, wc = wave & 3;
     const unsigned char *A = a.A, *W = a.W;
     const int M = a.M, N = a.N, K = a.K;
-    const int tiles_n = N / 256, tiles_m = (M + BM - 1) / BM, ntiles = tiles_m * tiles_n, per_xcd = (ntiles + 7) / 8;
+    const int tiles_n = N / 256, tiles_m = (M + BM - 1) / BM, tiles_z = tiles_m * tiles_n, ntiles = tiles_z * a.nz, per_xcd = (ntiles + 7) / 8;
     const int MB = 2 * ((M + 255) / 256), NB = N / 64;  // (mx_row_blocks_a)
     auto swz8 = [](int r, int c) { return r * RB + ((c ^ (r & 7)) << 4); };
-    auto tile_of = [&](int r, int &m0, int &n0) -> bool {
+    // (batch z slowest: what an XCD's workgroups hold at one time is a few W panels of one or two batch members and A)
+    auto tile_of = [&](int r, int &m0, int &n0, int &z) -> bool {
         const int L = blockIdx.x + r * gridDim.x, j = L >> 3, p = (L & 7) * per_xcd + j;
         if (j >= per_xcd || p >= ntiles) return false;
-        m0 = (p / tiles_n) * BM;
-        n0 = (p % tiles_n) * 256;
+        z = p / tiles_z;
+        const int q = p - z * tiles_z;
+        m0 = (q / tiles_n) * BM;
+        n0 = (q % tiles_n) * 256;
         return true;
     };
     // piece p of this wave in the A tile / the W tile: rows 8 * wave + 64 * p .. + 7; lane -> row lane >> 3, slot lane & 7,
@@ -176,16 +179,16 @@ __global__ __launch_bounds__(512) void gemm_mxfp8_256_kernel(GemmMxArgs a) {
     const uint2 *gsa = nullptr;
     const unsigned *gsw = nullptr;
     int sa_shift = 0;  // BM < 256: where the wave's RT scale bytes start in the 8-byte record of its 128-row block (bits)
-    auto point = [&](int m0, int n0) {
+    auto point = [&](int m0, int n0, int z) {
 #pragma unroll
         for (int pc = 0; pc < 4; ++pc) {
             const int row = 8 * wave + 64 * pc + (lane >> 3), chk = (lane & 7) ^ (row & 7);
             if (pc < AP) ga[pc] = A + (long)min(m0 + row, M - 1) * a.lda + chk * 16;
-            gw[pc] = W + (long)min(n0 + row, N - 1) * a.ldw + chk * 16;
+            gw[pc] = W + z * a.sW + (long)min(n0 + row, N - 1) * a.ldw + chk * 16;
         }
         const int mw = m0 + wr * (BM / 2);  // first row of the wave
         gsa = reinterpret_cast<const uint2 *>(a.SA) + ((long)(mw >> 7) * 64 + lane);
-        gsw = reinterpret_cast<const unsigned *>(a.SW) + ((long)((n0 >> 6) + wc) * 64 + lane);
+        gsw = reinterpret_cast<const unsigned *>(a.SW + z * a.sSW) + ((long)((n0 >> 6) + wc) * 64 + lane);
         sa_shift = 8 * ((mw >> 4) & 7);
     };
     const int nk = K / BK;
@@ -204,12 +207,12 @@ __global__ __launch_bounds__(512) void gemm_mxfp8_256_kernel(GemmMxArgs a) {
         for (int pc = 0; pc < 4; ++pc) __builtin_amdgcn_global_load_lds((gptr_t)(gw[pc] + off), (lptr_t)(sw + 64 * pc * RB), 16, 0, 0);
     };
     const int fr = lane & 15, fq = lane >> 4;
-    int m0 = 0, n0 = 0, round = 0;
-    bool have = tile_of(0, m0, n0);  // workgroup-uniform throughout
+    int m0 = 0, n0 = 0, z0 = 0, round = 0;
+    bool have = tile_of(0, m0, n0, z0);  // workgroup-uniform throughout
     uint2 sa_n = make_uint2(0, 0);   // the scales of the step in flight
     unsigned sw_n = 0;
     if (have) {
-        point(m0, n0);
+        point(m0, n0, z0);
         issue_a(0, 0);
         issue_w(0, 0);
         sa_n = gsa[0];
@@ -222,8 +225,8 @@ __global__ __launch_bounds__(512) void gemm_mxfp8_256_kernel(GemmMxArgs a) {
         for (int i = 0; i < RT; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
-        int m1 = 0, n1 = 0;
-        const bool have_next = tile_of(round + 1, m1, n1);
+        int m1 = 0, n1 = 0, z1 = 0;
+        const bool have_next = tile_of(round + 1, m1, n1, z1);
         for (int kt = 0; kt < nk; ++kt) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             int sa_lo = (int)sa_n.x, sa_hi = (int)sa_n.y, sw = (int)sw_n;
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(512) void gemm_mxfp8_256_kernel(GemmMxArgs a) {
             const unsigned char *la = lds + par * STAGE + wr * (ATILE / 2), *lw = lds + par * STAGE + ATILE + (wc >> 1) * HALF;
             const int wcol = (wc & 1) * 64;
             const bool last = kt + 1 == nk;
-            if (last && have_next) point(m1, n1);  // the loads below then fetch step 0 of the next tile
+            if (last && have_next) point(m1, n1, z1);  // the loads below then fetch step 0 of the next tile
             const bool more = !last || have_next;
             const int nkt = last ? 0 : kt + 1;
             if (more) {
@@ -276,13 +279,15 @@ __global__ __launch_bounds__(512) void gemm_mxfp8_256_kernel(GemmMxArgs a) {
             constexpr int SROW = 64 + 4;
             float *stg = reinterpret_cast<float *>(lds + (par ^ 1) * STAGE + wave * (16 * SROW * 4 + 256));
             const int ncol0 = n0 + wc * 64;
+            const float *bias_z = a.bias ? a.bias + z0 * a.sBias : nullptr;
+            const long c_off = z0 * a.sC;  // elements of the output type
             auto epilogue = [&](auto full_tag) {
                 constexpr bool FULL = decltype(full_tag)::value;
                 if constexpr (EPI == MXE_F32_RES) {
                     // (the row predicate stays on these stores on purpose: gemm.hip, fp32 epilogue)
-                    float *C = reinterpret_cast<float *>(a.C);
+                    float *C = reinterpret_cast<float *>(a.C) + c_off;
                     const int erow = lane >> 4, ecol = 4 * (lane & 15), nb = ncol0 + ecol;
-                    const float4 b4 = *reinterpret_cast<const float4 *>(a.bias ? a.bias + nb : a.epi_zero);
+                    const float4 b4 = *reinterpret_cast<const float4 *>(bias_z ? bias_z + nb : a.epi_zero);
 #pragma unroll
                     for (int i8 = 0; i8 < RT; ++i8) {
 #pragma unroll
@@ -310,8 +315,8 @@ __global__ __launch_bounds__(512) void gemm_mxfp8_256_kernel(GemmMxArgs a) {
                 } else {
                     // a lane takes 8 columns of a row, 8 lanes one row's 64 columns, 8 rows per instruction
                     const int erow = lane >> 3, ecol = 8 * (lane & 7), nb = ncol0 + ecol;
-                    const float *bp = a.bias ? a.bias + nb : a.epi_zero;
-                    const float4 b0 = *reinterpret_cast<const float4 *>(bp), b1 = *reinterpret_cast<const float4 *>(a.bias ? bp + 4 : bp);
+                    const float *bp = bias_z ? bias_z + nb : a.epi_zero;
+                    const float4 b0 = *reinterpret_cast<const float4 *>(bp), b1 = *reinterpret_cast<const float4 *>(bias_z ? bp + 4 : bp);
                     const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
                     unsigned long long scl[2] = {0ull, 0ull};  // MXE_MX_GELU: the scale bytes of rows erow, erow + 8 of the RT slices
 #pragma unroll
@@ -335,7 +340,7 @@ __global__ __launch_bounds__(512) void gemm_mxfp8_256_kernel(GemmMxArgs a) {
                                 if constexpr (EPI == MXE_MX_GELU) x[r] = gelu_mx(x[r]);
                             }
                             if constexpr (EPI == MXE_BF16) {
-                                bf16_t *C = reinterpret_cast<bf16_t *>(a.C);
+                                bf16_t *C = reinterpret_cast<bf16_t *>(a.C) + c_off;
                                 unsigned pk[4];
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) {
@@ -385,6 +390,7 @@ __global__ __launch_bounds__(512) void gemm_mxfp8_256_kernel(GemmMxArgs a) {
         }
         m0 = m1;
         n0 = n1;
+        z0 = z1;
         have = have_next;
         ++round;
     }
@@ -442,9 +448,12 @@ void launch_gemm_mx(const GemmMxArgs &args, int epi, hipStream_t st) {
     MW_CHECK(a.ldc >= a.N, "gemm (mx): output stride");
     a.epi_zero = epi_zero_device();
     // the largest tile height that still gives the 256 CUs about a tile each (M = 1500: 64 or 128 rows; batched passes: 256)
-    const long nt = a.N / 256;
+    MW_CHECK(a.nz >= 1 && (a.nz == 1 || (epi == MXE_BF16 && a.sW % 16 == 0 && a.sSW % 4 == 0 && a.sC % 8 == 0 && a.sBias % 4 == 0)),
+             "gemm (mx): batch strides (bf16 rows only)");
+    const long nt = (long)(a.N / 256) * a.nz;
     const int bm = nt * ceil_div(a.M, 256) >= 200 ? 256 : nt * ceil_div(a.M, 128) >= 200 ? 128 : 64;
     const long tiles = nt * ceil_div(a.M, bm);
+    MW_CHECK(tiles < (1L << 28), "gemm (mx): tile count");
     const dim3 pgrid((unsigned)std::min<long>(ceil_div<long>(tiles, 8) * 8, 256));
 #define MX_LAUNCH(EPIv)                                                                                                     \
     do {                                                                                                                    \

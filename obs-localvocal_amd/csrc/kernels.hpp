@@ -110,6 +110,10 @@ struct GemmMxArgs {
     long lda = 0, ldw = 0, ldc = 0, ldr = 0;
     int M = 0, N = 0, K = 0;
     float alpha = 1.0f;
+    // batch (MXE_BF16 only): member z multiplies the same A with W + z sW (bytes), scales SW + z sSW (bytes), bias + z sBias
+    // (floats), into C + z sC (elements) — the cross K / V of all decoder layers in one launch
+    int nz = 1;
+    long sW = 0, sSW = 0, sC = 0, sBias = 0;
     const float *epi_zero = nullptr;  // set by the launcher
 };
 // C = epilogue(alpha * A W^T + bias): 256 x 256 persistent tiles, K % 128 == 0, N % 256 == 0

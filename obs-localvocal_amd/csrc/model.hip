@@ -427,7 +427,7 @@ void load_model(Model &m, const unsigned char *data, size_t size, DType wt, hipS
     m.enc_mx = fp8 >= 2;
     if (m.enc_mx && d % 256 != 0) throw std::runtime_error("MX-fp8 encoder: n_audio_state must be a multiple of 256");
     if (m.enc_mx)  // Q|K (2 d^2), fc1 and fc2 (8 d^2) as bytes + one scale byte per 32
-        m.arena_size += Le * (10 * d * d + 10 * d * d / 32 + 6 * 256);
+        m.arena_size += Le * (10 * d * d + 10 * d * d / 32 + 6 * 256) + Ld * (2 * d * d + 2 * d * d / 32) + 2 * 256;
     MW_HIP(hipMalloc((void **)&m.arena, m.arena_size));
     m.arena_owner = std::shared_ptr<void>(m.arena, free_device_block);
     L.staging_size = max_bytes;
@@ -511,6 +511,13 @@ void load_model(Model &m, const unsigned char *data, size_t size, DType wt, hipS
             }
         }
         if (fp8) L.quantize(m.tok_emb, (size_t)hp.n_vocab, d, m.tok_emb8, m.tok_emb_s);
+        if (m.enc_mx) {  // the cross K / V projections read the encoder's output: MX-fp8 as well, one scale array per matrix
+            const size_t sb = mx_scale_bytes_w((int)d, (int)d);
+            m.ckv_w8 = (unsigned char *)L.alloc(Ld * 2 * d * d);
+            m.ckv_s8 = (unsigned char *)L.alloc(Ld * 2 * sb);
+            for (size_t i = 0; i < Ld * 2; ++i)
+                launch_quantize_mx_weights((const char *)m.ckv_w + i * d * d * ws, (int)d, (int)d, m.ckv_w8 + i * d * d, m.ckv_s8 + i * sb, st);
+        }
         m.dec_ln_w = L.vec("decoder.ln.weight", d);
         m.dec_ln_b = L.vec("decoder.ln.bias", d);
         MelTables tab;

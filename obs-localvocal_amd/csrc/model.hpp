@@ -106,6 +106,7 @@ struct Model {
     // AND activations with one power-of-two scale per block of 32 along k, on v_mfma_scale_f32_16x16x128_f8f6f4.  The
     // bf16 copies are kept (V, attention output, conv stem and cross K / V stay bf16).  Needs n_audio_state % 256 == 0.
     bool enc_mx = false;
+    unsigned char *ckv_w8 = nullptr, *ckv_s8 = nullptr;  // enc_mx: the cross K | V weights [L][2][d][d] as e4m3 + block scales per matrix
     unsigned char *tok_emb8 = nullptr;
     float *tok_emb_s = nullptr;
     // device arena

@@ -559,19 +559,19 @@ void encode(ow_context &c, int mel_offset) {
     std::vector<float> h((size_t)n_ctx * d), q((size_t)n_ctx * d), k((size_t)n_ctx * d), v((size_t)n_ctx * d),
         att((size_t)n_ctx * d), tmp((size_t)n_ctx * d), ff((size_t)n_ctx * 4 * d);
     const float kq_scale = 1.0f / sqrtf((float)dh);
+    // MX twin: weights and the activation operand of the Q, K, fc1, fc2 products on the MX-fp8 grid; V reads h as it is
+    auto mxw = [&](const std::string &name, int K) -> const float * {
+        if (!c.mx_encoder) return m.get(name).data();
+        auto it = c.mx_weights.find(name);
+        if (it == c.mx_weights.end()) {
+            it = c.mx_weights.emplace(name, m.get(name)).first;
+            mx_qdq_rows(it->second.data(), it->second.size() / K, K, K);
+        }
+        return it->second.data();
+    };
     for (int l = 0; l < hp.n_audio_layer; ++l) {
         const std::string p = "encoder.blocks." + std::to_string(l) + ".";
         layer_norm(h.data(), x.data(), m.get(p + "attn_ln.weight").data(), m.get(p + "attn_ln.bias").data(), n_ctx, d);
-        // MX twin: weights and the activation operand of the Q, K, fc1, fc2 products on the MX-fp8 grid; V reads h as it is
-        auto mxw = [&](const std::string &name, int K) -> const float * {
-            if (!c.mx_encoder) return m.get(name).data();
-            auto it = c.mx_weights.find(name);
-            if (it == c.mx_weights.end()) {
-                it = c.mx_weights.emplace(name, m.get(name)).first;
-                mx_qdq_rows(it->second.data(), it->second.size() / K, K, K);
-            }
-            return it->second.data();
-        };
         const float *hq = h.data();
         if (c.mx_encoder) {
             hmx = h;
@@ -628,16 +628,21 @@ void encode(ow_context &c, int mel_offset) {
     // cross-KV: K = (Wk enc) * dh^-0.25, V = Wv enc + bv
     const int dt = hp.n_text_state, dht = dt / hp.n_text_head;
     const float kscale = powf((float)dht, -0.25f);
+    const float *eq = c.enc_out.data();  // MX twin: the cross K / V products read the encoder's output on the MX-fp8 grid
+    if (c.mx_encoder) {
+        hmx = c.enc_out;
+        mx_qdq_rows(hmx.data(), n_ctx, d, d);
+        eq = hmx.data();
+    }
     c.cross_k.assign(hp.n_text_layer, {});
     c.cross_v.assign(hp.n_text_layer, {});
     for (int l = 0; l < hp.n_text_layer; ++l) {
         const std::string p = "decoder.blocks." + std::to_string(l) + ".cross_attn.";
         c.cross_k[l].resize((size_t)n_ctx * dt);
         c.cross_v[l].resize((size_t)n_ctx * dt);
-        matmul_nt(c.cross_k[l].data(), dt, c.enc_out.data(), d, m.get(p + "key.weight").data(), d, nullptr, n_ctx, dt, d);
+        matmul_nt(c.cross_k[l].data(), dt, eq, d, mxw(p + "key.weight", d), d, nullptr, n_ctx, dt, d);
         for (auto &f : c.cross_k[l]) f *= kscale;
-        matmul_nt(c.cross_v[l].data(), dt, c.enc_out.data(), d, m.get(p + "value.weight").data(), d,
-                  m.get(p + "value.bias").data(), n_ctx, dt, d);
+        matmul_nt(c.cross_v[l].data(), dt, eq, d, mxw(p + "value.weight", d), d, m.get(p + "value.bias").data(), n_ctx, dt, d);
     }
 }
 

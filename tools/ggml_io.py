@@ -391,8 +391,10 @@ MX_ENCODER_SUFFIXES = (".attn.query.weight", ".attn.key.weight", ".mlp.0.weight"
 
 
 def is_mx_encoder_tensor(name: str) -> bool:
-    """The encoder matrices MW_PRECISION_FP8_MX multiplies in MX-fp8: Q, K, fc1, fc2 of every block."""
-    return name.startswith("encoder.blocks.") and name.endswith(MX_ENCODER_SUFFIXES)
+    """The matrices MW_PRECISION_FP8_MX multiplies in MX-fp8: Q, K, fc1, fc2 of every encoder block and the decoder layers'
+    cross K / V projections of the encoder's output."""
+    return (name.startswith("encoder.blocks.") and name.endswith(MX_ENCODER_SUFFIXES)) or \
+        (name.startswith("decoder.blocks.") and name.endswith((".cross_attn.key.weight", ".cross_attn.value.weight")))
 
 
 def mxfp8_quantize_dequantize(a: np.ndarray) -> np.ndarray:

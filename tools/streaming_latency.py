@@ -43,7 +43,7 @@ def main():
     ap.add_argument("--model", default="large-v3")
     ap.add_argument("--seconds", type=float, default=64.0)
     ap.add_argument("--tokens", type=int, default=12)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp8"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp8", "fp8mx"])
     ap.add_argument("--vad", default="silero", choices=["silero", "gate"])
     ap.add_argument("--model-dir", default=os.environ.get("MI355_WHISPER_BENCH_DIR", "/tmp/mi355_whisper_bench"))
     a = ap.parse_args()
@@ -52,7 +52,7 @@ def main():
     path = os.path.join(a.model_dir, f"ggml-{a.model}-synth-s1234.bin")
     if not os.path.exists(path):
         synth_large.write_large(path, a.model, seed=1234, quiet_special=True)
-    f = pkg.Filter(precision=pkg.PRECISION_FP8 if a.precision == "fp8" else pkg.PRECISION_BF16)
+    f = pkg.Filter(precision={"bf16": pkg.PRECISION_BF16, "fp8": pkg.PRECISION_FP8, "fp8mx": pkg.PRECISION_FP8_MX}[a.precision])
     t_req, lat = {}, []
 
     def on_request(pcm, t0, t1, vs):
@@ -93,7 +93,7 @@ def main():
         return {"calls": int(len(v)), "p50_ms": round(float(np.percentile(v, 50)), 2), "p95_ms": round(float(np.percentile(v, 95)), 2),
                 "max_ms": round(float(v[-1]), 2)} if len(v) else {"calls": 0}
 
-    out = {"workload": f"{a.model} {'e4m3 decoder weights, bf16 activations' if a.precision == 'fp8' else 'bf16'} beam 5, {a.seconds:.0f} s speech-like stream, VAD active ({'Silero network on the GPU, synthetic weights' if a.vad == 'silero' else 'energy gate'}), partials every 1100 ms, "
+    out = {"workload": f"{a.model} { {'fp8': 'e4m3 decoder weights, bf16 activations', 'fp8mx': 'e4m3 decoder weights + MX-fp8 encoder products', 'bf16': 'bf16'}[a.precision] } beam 5, {a.seconds:.0f} s speech-like stream, VAD active ({'Silero network on the GPU, synthetic weights' if a.vad == 'silero' else 'energy gate'}), partials every 1100 ms, "
                        f"{a.tokens} forced tokens per call",
            "all": stats([l for l, _, _ in lat]), "partial": stats([l for l, vs, _ in lat if vs == 3]),
            "final": stats([l for l, vs, _ in lat if vs != 3]),
