@@ -253,27 +253,15 @@ def test_large_v3_dims_fp8_weights_teacher_forced(pkg, big_model):
     _teacher_forced(pkg, big_model("large-v3", fp8_decoder=True), n_rows=5, steps=8, precision=pkg.PRECISION_FP8)
 
 
-@pytest.mark.parametrize("mode", ["active", "hybrid"])
-def test_config4_streaming_partials_large_v3_fp8_through_whisper_loop(pkg, big_model, tmp_path, mode):
-    """BASELINE configs[4] as ONE thing: large-v3 dims, e4m3 decoder weights, the Silero network on the GPU gating 3 s
-    segments with partials every 1100 ms, everything through the worker thread (whisper_loop ->
-    vad_based_segmentation -> run_inference_and_callbacks -> run_whisper_inference -> whisper_full;
-    /root/reference/src/whisper-utils/whisper-processing.cpp:326-431, vad-processing.cpp:202-367).
-      * the inference requests (PCM bytes, timestamps, VAD state) are those of the segmentation restatement driven by the
-        restated network;
-      * per request the fp8 filter returns what a bf16 filter returns on the same file: result enum, text, kept tokens with
-        their probabilities and the full whisper_full token sequence, equal to the bit (e4m3 -> bf16 is exact and the row
-        scales are powers of two, DESIGN.md section 3; the model arithmetic itself is pinned by the teacher-forced test above).
-    12 forced tokens per call, beam 5 (the plugin's default strategy), temperature fallback off.  VAD mode ACTIVE cuts at the
-    network's speech ends (segment_duration is not read in that mode, vad-processing.cpp:202-367); HYBRID adds the 3 s cap
-    of segment_duration (vad-processing.cpp:369-454)."""
+def _config4_runner(pkg, path, tmp_path, mode):
+    """-> (run(precision) -> (requests, results), sg): one filter life through whisper_loop on a 20 s speech-like stream; run()
+    asserts that the inference requests are those of the segmentation restatement driven by the restated Silero network"""
     import time
 
     from oracle import segmentation_oracle as sg
     from oracle import silero_vad_oracle as so
     from test_segmentation_cpu import speechlike
 
-    path = big_model("large-v3", fp8_decoder=True)
     w = so.synth_weights(11)
     vad_path = str(tmp_path / "silero_synth.onnx")
     so.write_onnx(vad_path, w)
@@ -290,7 +278,7 @@ def test_config4_streaming_partials_large_v3_fp8_through_whisper_loop(pkg, big_m
 
     def run(precision):
         import ctypes
-        ctypes.CDLL(None).srand(1234)   # requests under 1 s are centred in rand() noise (whisper-processing.cpp:162-180): same stream for both runs
+        libc = ctypes.CDLL(None)
         f = pkg.Filter(precision=precision)
         requests, results = [], []
 
@@ -313,6 +301,10 @@ def test_config4_streaming_partials_large_v3_fp8_through_whisper_loop(pkg, big_m
                                      segment_duration=3000, vad=sg.VadIteratorOracle(prob_source=so.SileroOracle(w)))
             for i in range(0, len(x), 4000):   # lock-step with the worker, as the offline harness feeds (one pass per packet)
                 ts = 1_000_000_000 + i * 1_000_000_000 // 16000
+                # requests under 1 s are centred in rand() noise (whisper-processing.cpp:162-180).  rand() is process-global
+                # and the HIP runtime draws from it too while it initialises (a first run in a fresh process differed from
+                # the second at the first short request): re-seeded before every packet, so every run pads alike
+                libc.srand(1234)
                 assert f.push_packet([x[i:i + 4000]], ts) == 0
                 orc.push_packet(x[i:i + 4000], ts)
                 orc.step()
@@ -326,6 +318,24 @@ def test_config4_streaming_partials_large_v3_fp8_through_whisper_loop(pkg, big_m
         finally:
             f.close()
 
+    return run, sg
+
+
+@pytest.mark.parametrize("mode", ["active", "hybrid"])
+def test_config4_streaming_partials_large_v3_fp8_through_whisper_loop(pkg, big_model, tmp_path, mode):
+    """BASELINE configs[4] as ONE thing: large-v3 dims, e4m3 decoder weights, the Silero network on the GPU gating 3 s
+    segments with partials every 1100 ms, everything through the worker thread (whisper_loop ->
+    vad_based_segmentation -> run_inference_and_callbacks -> run_whisper_inference -> whisper_full;
+    /root/reference/src/whisper-utils/whisper-processing.cpp:326-431, vad-processing.cpp:202-367).
+      * the inference requests (PCM bytes, timestamps, VAD state) are those of the segmentation restatement driven by the
+        restated network;
+      * per request the fp8 filter returns what a bf16 filter returns on the same file: result enum, text, kept tokens with
+        their probabilities and the full whisper_full token sequence, equal to the bit (e4m3 -> bf16 is exact and the row
+        scales are powers of two, DESIGN.md section 3; the model arithmetic itself is pinned by the teacher-forced test above).
+    12 forced tokens per call, beam 5 (the plugin's default strategy), temperature fallback off.  VAD mode ACTIVE cuts at the
+    network's speech ends (segment_duration is not read in that mode, vad-processing.cpp:202-367); HYBRID adds the 3 s cap
+    of segment_duration (vad-processing.cpp:369-454)."""
+    run, sg = _config4_runner(pkg, big_model("large-v3", fp8_decoder=True), tmp_path, mode)
     req8, res8 = run(pkg.PRECISION_FP8)
     req16, res16 = run(pkg.PRECISION_BF16)
     n_partial = sum(vs == sg.VAD_STATE_PARTIAL for _, _, _, vs in req8)
@@ -338,3 +348,18 @@ def test_config4_streaming_partials_large_v3_fp8_through_whisper_loop(pkg, big_m
     assert len({tuple(r["all_tokens"]) for r in res8}) > 1                   # ... and the chunks lead to different transcripts
     for k, (a, b) in enumerate(zip(res8, res16)):
         assert a == b, f"request {k} ({len(req8[k][0])} samples, VAD state {req8[k][3]})"
+
+
+def test_config4_streaming_partials_with_the_mx_fp8_encoder_through_whisper_loop(pkg, big_model, tmp_path):
+    """configs[4] with MW_PRECISION_FP8_MX (e4m3 decoder weights + the encoder's large products in MX-fp8): the same stream
+    through the same worker.  The requests are the restatement's (asserted by the runner); the results cannot equal the
+    bf16 filter's (the encoder computes in another format: tests/test_gpu_mx_encoder.py holds it to its own rule) — what
+    is asserted is that the mode is deterministic through the worker (two filter lives give the same results: a window
+    encodes to the same bits whichever tile height its pass chose) and that it produces transcripts."""
+    run, sg = _config4_runner(pkg, big_model("large-v3", fp8_decoder=True), tmp_path, "active")
+    req_a, res_a = run(pkg.PRECISION_FP8_MX)
+    req_b, res_b = run(pkg.PRECISION_FP8_MX)
+    assert len(req_a) == len(req_b) >= 6
+    assert all(len(r["all_tokens"]) >= 1 for r in res_a) and len({tuple(r["all_tokens"]) for r in res_a}) > 1
+    for k, (a, b) in enumerate(zip(res_a, res_b)):
+        assert a == b, f"request {k}"
