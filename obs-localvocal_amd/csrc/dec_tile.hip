@@ -564,8 +564,8 @@ __device__ __forceinline__ void logits_tile(const bf16_t *W, const unsigned char
 // load level than the single-context form; the rows of a step may belong to different contexts).
 template <typename OT, bool DESC>
 __device__ __forceinline__ void self_attn_lean(const float *q, const bf16_t *kc, const bf16_t *vc, const int *slot, const int *pos,
-                                               const int *kv_idx, const StepRow *rows, long kv_layer_off, OT *out, int H, int d, int TC,
-                                               float *red, float *sm) {
+                                               const int *kv_idx, const StepRow *rows, const int *phys, long kv_layer_off, OT *out, int H,
+                                               int d, int TC, float *red, float *sm) {
     constexpr int PVI = TILE_TC_MAX / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, jj = tid >> 3, e8 = tid & 7;
     const int r = blockIdx.x / H, h = blockIdx.x - r * H;
@@ -581,12 +581,21 @@ __device__ __forceinline__ void self_attn_lean(const float *q, const bf16_t *kc,
         np = pos[r] + 1;
         sl = slot[r];
     }
-    const int *idx = kv_idx + (long)sl * TC;
     const float4 qa = *reinterpret_cast<const float4 *>(q + (long)r * d + h * 64 + e8 * 8);
     const float4 qb = *reinterpret_cast<const float4 *>(q + (long)r * d + h * 64 + e8 * 8 + 4);
     int iv[PVI];
+    if constexpr (DESC) {
+        // the row's physical slot per position, laid out by the step's first kernel (step_begin_batch_kernel: the index-table
+        // entries this loop used to fetch behind the row's descriptor, padded with the last valid one): its address depends
+        // on nothing loaded here, so descriptor, q and these travel together and the K / V loads are the second round trip,
+        // not the third
 #pragma unroll
-    for (int i = 0; i < PVI; ++i) iv[i] = idx[min(jj + 64 * i, np - 1)];
+        for (int i = 0; i < PVI; ++i) iv[i] = phys[(long)r * TILE_TC_MAX + jj + 64 * i];
+    } else {
+        const int *idx = kv_idx + (long)sl * TC;
+#pragma unroll
+        for (int i = 0; i < PVI; ++i) iv[i] = idx[min(jj + 64 * i, np - 1)];
+    }
     uint4 kq[PVI], vq[PVI];
 #pragma unroll
     for (int i = 0; i < PVI; ++i) {
@@ -878,10 +887,10 @@ __global__ __launch_bounds__(MT) void logits_tile_kernel(const bf16_t *W, const 
 template <typename OT, bool DESC>
 __global__ __launch_bounds__(MT) void self_attn_lean_kernel(const float *q, const bf16_t *kc, const bf16_t *vc, const int *slot,
                                                                        const int *pos, const int *kv_idx, const StepRow *rows,
-                                                                       long kv_layer_off, OT *out, int H, int d, int TC) {
+                                                                       const int *phys, long kv_layer_off, OT *out, int H, int d, int TC) {
     __shared__ __attribute__((aligned(16))) float red[8 * 64];
     __shared__ float sm[16];
-    self_attn_lean<OT, DESC>(q, kc, vc, slot, pos, kv_idx, rows, kv_layer_off, out, H, d, TC, red, sm);
+    self_attn_lean<OT, DESC>(q, kc, vc, slot, pos, kv_idx, rows, phys, kv_layer_off, out, H, d, TC, red, sm);
 }
 
 
@@ -914,7 +923,8 @@ __global__ __launch_bounds__(MT) void cross_attn_lean_kernel(const float *q, con
 // embed one token each; the last block copies the StepBlock into device memory for the kernels behind.
 __global__ __launch_bounds__(256) void step_begin_batch_kernel(const StepBlock *__restrict__ hblk, StepBlock *__restrict__ dblk, int n_rows,
                                                                int n_groups, int n_text_ctx, const bf16_t *__restrict__ te,
-                                                               const float *__restrict__ pe, float *__restrict__ x, int d) {
+                                                               const float *__restrict__ pe, float *__restrict__ x, int d,
+                                                               int *__restrict__ phys) {
     const int b = blockIdx.x;
     if (b < n_groups * KV_SLOTS) {
         const int g = b / KV_SLOTS, j = b - g * KV_SLOTS;
@@ -928,6 +938,18 @@ __global__ __launch_bounds__(256) void step_begin_batch_kernel(const StepBlock *
         const int i = b - n_groups * KV_SLOTS;
         const long t = hblk->rows[i].token, p = hblk->rows[i].pos;
         for (int e = threadIdx.x; e < d; e += 256) x[(long)i * d + e] = __uint_as_float((unsigned)te[t * d + e] << 16) + pe[p * d + e];
+        // the row's physical slot per position for the self-attention kernels of every layer (self_attn_lean): what they
+        // would read from the row's index table AFTER this kernel's reshuffle blocks — taken from the reshuffle's source
+        // where the reshuffle writes (those blocks run beside this one), positions beyond the row's own padded with its last
+        const StepRow *Rw = &hblk->rows[i];
+        const StepGroup *G = &hblk->groups[Rw->group];
+        const int sl = Rw->slot, np = (int)p + 1, src = G->src[sl], rnp = G->reorder_n_past;
+        const bool re = G->reorder_flag != 0 && src >= 0;
+        const int *cur = Rw->kv_idx + (long)sl * n_text_ctx, *old = G->idx_old + (long)(src < 0 ? 0 : src) * n_text_ctx;
+        for (int k = threadIdx.x; k < TILE_TC_MAX; k += 256) {
+            const int pp = min(k, np - 1);
+            phys[(long)i * TILE_TC_MAX + k] = re && pp <= rnp ? (pp < rnp ? old[pp] : sl) : cur[pp];
+        }
     } else {
         const int *src = reinterpret_cast<const int *>(hblk);
         int *dst = reinterpret_cast<int *>(dblk);
@@ -1044,21 +1066,22 @@ void launch_proj_batch(const GemvArgs &a, const StepBlock *blk, long kv_layer_of
 }
 
 void launch_step_begin_batch(const StepBlock *h_block_dev, StepBlock *d_block, int n_rows, int n_groups, int n_text_ctx,
-                             const void *tok_emb, const float *pos_emb, float *x, int d, hipStream_t st) {
-    MW_CHECK(h_block_dev && d_block && n_rows >= 1 && n_rows <= STEP_MAX_ROWS && n_groups >= 1 && n_groups <= STEP_MAX_GROUPS,
+                             const void *tok_emb, const float *pos_emb, float *x, int d, int *row_phys, hipStream_t st) {
+    MW_CHECK(h_block_dev && d_block && row_phys && n_rows >= 1 && n_rows <= STEP_MAX_ROWS && n_groups >= 1 && n_groups <= STEP_MAX_GROUPS &&
+                 n_text_ctx <= TILE_TC_MAX,
              "step_begin_batch: rows / groups");
     static_assert(sizeof(StepBlock) % sizeof(int) == 0, "StepBlock is copied int by int");
     hipLaunchKernelGGL(step_begin_batch_kernel, dim3(n_groups * KV_SLOTS + n_rows + 1), dim3(256), 0, st, h_block_dev, d_block, n_rows,
-                       n_groups, n_text_ctx, (const bf16_t *)tok_emb, pos_emb, x, d);
+                       n_groups, n_text_ctx, (const bf16_t *)tok_emb, pos_emb, x, d, row_phys);
     MW_HIP(hipGetLastError());
 }
 
-void launch_self_attn_batch(const float *q, const StepBlock *blk, long kv_layer_off, void *out, int n, int H, int d, int n_text_ctx,
-                            hipStream_t st) {
-    MW_CHECK(blk && n >= 1 && n <= STEP_MAX_ROWS && H >= 1 && d == H * 64 && n_text_ctx <= TILE_TC_MAX, "self_attn_batch: shape");
+void launch_self_attn_batch(const float *q, const StepBlock *blk, const int *row_phys, long kv_layer_off, void *out, int n, int H, int d,
+                            int n_text_ctx, hipStream_t st) {
+    MW_CHECK(blk && row_phys && n >= 1 && n <= STEP_MAX_ROWS && H >= 1 && d == H * 64 && n_text_ctx <= TILE_TC_MAX, "self_attn_batch: shape");
     hipLaunchKernelGGL((self_attn_lean_kernel<bf16_t, true>), dim3(n * H), dim3(MT), 0, st, q, (const bf16_t *)nullptr, (const bf16_t *)nullptr,
-                       (const int *)nullptr, (const int *)nullptr, (const int *)nullptr, blk->rows, kv_layer_off, (bf16_t *)out, H, d,
-                       n_text_ctx);
+                       (const int *)nullptr, (const int *)nullptr, (const int *)nullptr, blk->rows, row_phys, kv_layer_off, (bf16_t *)out,
+                       H, d, n_text_ctx);
     MW_HIP(hipGetLastError());
 }
 
@@ -1126,10 +1149,10 @@ void launch_self_attn_wg(const float *q, const void *kcache, const void *vcache,
     MW_CHECK(n >= 1 && H >= 1 && d == H * 64 && n_text_ctx <= TILE_TC_MAX, "self_attn_wg: shape");
     if (out_t == DType::F32)
         hipLaunchKernelGGL((self_attn_lean_kernel<float, false>), dim3(n * H), dim3(MT), 0, st, q, (const bf16_t *)kcache, (const bf16_t *)vcache,
-                           d_slot, d_pos, d_kv_idx, (const StepRow *)nullptr, 0L, (float *)out, H, d, n_text_ctx);
+                           d_slot, d_pos, d_kv_idx, (const StepRow *)nullptr, (const int *)nullptr, 0L, (float *)out, H, d, n_text_ctx);
     else
         hipLaunchKernelGGL((self_attn_lean_kernel<bf16_t, false>), dim3(n * H), dim3(MT), 0, st, q, (const bf16_t *)kcache, (const bf16_t *)vcache,
-                           d_slot, d_pos, d_kv_idx, (const StepRow *)nullptr, 0L, (bf16_t *)out, H, d, n_text_ctx);
+                           d_slot, d_pos, d_kv_idx, (const StepRow *)nullptr, (const int *)nullptr, 0L, (bf16_t *)out, H, d, n_text_ctx);
     MW_HIP(hipGetLastError());
 }
 

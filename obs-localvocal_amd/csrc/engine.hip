@@ -228,7 +228,7 @@ Hub::~Hub() {
     for (EncLane &el : enc_lanes)
         if (el.st) (void)hipStreamSynchronize(el.st);
     for (Lane &ln : lanes) {
-        void *ptrs[] = {ln.d_blk, ln.d_x, ln.d_q, ln.d_part, ln.d_logits, ln.d_work, ln.d_attd, ln.d_ffd, ln.d_head_cnt, ln.d_suppress};
+        void *ptrs[] = {ln.d_blk, ln.d_x, ln.d_q, ln.d_part, ln.d_logits, ln.d_work, ln.d_attd, ln.d_ffd, ln.d_head_cnt, ln.d_suppress, ln.d_phys};
         for (void *p : ptrs)
             if (p) (void)hipFree(p);
         if (ln.h_blk) (void)hipHostFree(ln.h_blk);
@@ -276,6 +276,7 @@ std::shared_ptr<Hub> create_hub(const Model &m, int device, bool use_graphs) {
         dev_alloc(ln.d_logits, R * nv);
         dev_alloc(ln.d_work, process_logits_work_floats((int)R, (int)nv));
         dev_alloc(ln.d_suppress, nv);
+        dev_alloc(ln.d_phys, (size_t)STEP_MAX_ROWS * TILE_TC_MAX);
         dev_alloc(ln.d_head_cnt, (size_t)STEP_MAX_GROUPS * 64);
         MW_HIP(hipMemsetAsync(ln.d_head_cnt, 0, (size_t)STEP_MAX_GROUPS * 64 * sizeof(unsigned), ln.st));
     }
@@ -643,7 +644,7 @@ void Hub::run(Lane &ln, const std::vector<StepRequest *> &batch) {
     const size_t kv_layer = (size_t)KV_SLOTS * TC * d;
     const float qk_scale = powf(64.0f, -0.25f);
     auto enqueue = [&]() {
-        launch_step_begin_batch(h_blk_dev, d_blk, R, G, TC, m.tok_emb, m.dec_pe, d_x, d, st);
+        launch_step_begin_batch(h_blk_dev, d_blk, R, G, TC, m.tok_emb, m.dec_pe, d_x, d, ln.d_phys, st);
         auto bracket = [&](int tag, auto &&launch) {
             const bool prof = pc && tag == prof_tag && pc->prof_n + 2 <= (int)pc->prof_ev.size();
             if (prof) MW_HIP(hipEventRecord(pc->prof_ev[pc->prof_n++], st));
@@ -667,8 +668,8 @@ void Hub::run(Lane &ln, const std::vector<StepRequest *> &batch) {
                 g.kv_t = DType::BF16; g.n_text_ctx = TC; g.tag = GEMV_QKV;
                 proj(g, kv_off);
             }
-            bracket(GEMV_N_TAGS, [&]() { launch_self_attn_batch(d_q, d_blk, kv_off, d_attd, R, H, d, TC, st); });
-            if (dup_tag == GEMV_N_TAGS && prof_tag < 0) launch_self_attn_batch(d_q, d_blk, kv_off, d_attd, R, H, d, TC, st);
+            bracket(GEMV_N_TAGS, [&]() { launch_self_attn_batch(d_q, d_blk, ln.d_phys, kv_off, d_attd, R, H, d, TC, st); });
+            if (dup_tag == GEMV_N_TAGS && prof_tag < 0) launch_self_attn_batch(d_q, d_blk, ln.d_phys, kv_off, d_attd, R, H, d, TC, st);
             {
                 GemvArgs g;
                 g.x = (const float *)d_attd; g.x_bf16 = 1; g.ldx = d; g.n = R; g.W = e.out_w; if (m.dec_fp8) { g.W8 = e.out_w8; g.w_scale = e.out_s; } g.bias = e.out_b; g.N = d; g.K = d;

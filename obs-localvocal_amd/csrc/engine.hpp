@@ -97,6 +97,7 @@ struct Hub {
         float *d_x = nullptr, *d_q = nullptr, *d_part = nullptr, *d_logits = nullptr, *d_work = nullptr;
         void *d_attd = nullptr, *d_ffd = nullptr;
         unsigned *d_head_cnt = nullptr;
+        int *d_phys = nullptr;  // [STEP_MAX_ROWS][TILE_TC_MAX] physical KV slot per (row, position) of the step (step_begin_batch_kernel)
         LogitsRowResult *h_res = nullptr, *h_res_dev = nullptr;  // pinned: the sampler stores its results straight into it
         unsigned char *d_suppress = nullptr;  // the suppression mask of the lane's last rules (copied from the leader when the key changes)
         std::string suppress_key;

@@ -257,12 +257,13 @@ constexpr int TILE_TC_MAX = 448;         // text positions one self-attention pa
 // head of the step: block from pinned host memory (device view) -> per-request index-table updates, token embeddings of
 // the rows into x, and the block's copy into device memory
 void launch_step_begin_batch(const StepBlock *h_block_dev, StepBlock *d_block, int n_rows, int n_groups, int n_text_ctx,
-                             const void *tok_emb, const float *pos_emb, float *x, int d, hipStream_t st);
+                             const void *tok_emb, const float *pos_emb, float *x, int d, int *row_phys, hipStream_t st);
 // GemvArgs contract of launch_proj_wg for n <= STEP_MAX_ROWS rows; the qkv class writes K / V through blk->rows[i] + kv_layer_off
 // (element offset of the layer inside a context's cache)
 void launch_proj_batch(const GemvArgs &a, const StepBlock *blk, long kv_layer_off, hipStream_t st);
-void launch_self_attn_batch(const float *q, const StepBlock *blk, long kv_layer_off, void *out, int n, int H, int d, int n_text_ctx,
-                            hipStream_t st);
+// row_phys [STEP_MAX_ROWS][TILE_TC_MAX]: every row's physical KV slot per position, written by launch_step_begin_batch
+void launch_self_attn_batch(const float *q, const StepBlock *blk, const int *row_phys, long kv_layer_off, void *out, int n, int H, int d,
+                            int n_text_ctx, hipStream_t st);
 // cross-attention of every request's rows over its own context's K / V (element offsets of the layer's K and V inside
 // a context's cross buffer); head_cnt: n_groups * H zeroed counters, left zeroed
 void launch_cross_attn_batch(const float *q, const StepBlock *blk, long k_off, long v_off, float *partial, void *out,
