@@ -39,16 +39,17 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
 }
 
 __global__ __launch_bounds__(256) void enc_flash_attn_kernel(const bf16_t *__restrict__ qk, const bf16_t *__restrict__ vt,
-                                                             bf16_t *__restrict__ out, int n_ctx, int tp, int d, float scale_log2) {
+                                                             bf16_t *__restrict__ out, int n_ctx, int tp, int d, float scale_log2,
+                                                             int ldq_) {
     // blockIdx.z: window of a batched encoder pass (each window has its own Q|K, V^T and output slab, back to back)
-    qk += (long)blockIdx.z * n_ctx * 2 * d;
+    qk += (long)blockIdx.z * n_ctx * ldq_;
     vt += (long)blockIdx.z * d * tp;
     out += (long)blockIdx.z * n_ctx * d;
     __shared__ __attribute__((aligned(16))) bf16_t kt[2][FK * FLD];
     __shared__ __attribute__((aligned(16))) bf16_t vs[2][64 * FLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
     const int h = blockIdx.y, q0 = blockIdx.x * FQ + wave * 32;
-    const long ldq = 2L * d;
+    const long ldq = ldq_;  // 2 d (Q | K rows) or 3 d (Q | K | V rows of the MX-fp8 mode)
     // Q fragments of the wave's two query tiles (loop invariant)
     uint4 qf[2][2];
 #pragma unroll
@@ -201,12 +202,15 @@ __global__ __launch_bounds__(256) void enc_flash_attn_kernel(const bf16_t *__res
 
 }  // namespace
 
-void launch_enc_flash_attn(const void *qk, const void *vt, void *out, int n_ctx, int tp, int d, int H, hipStream_t st, int n_windows) {
-    MW_CHECK(qk && vt && out && n_ctx > 0 && d == H * 64 && tp % FK == 0 && tp >= n_ctx && tp - n_ctx < FK, "enc_flash_attn: shape");
+void launch_enc_flash_attn(const void *qk, const void *vt, void *out, int n_ctx, int tp, int d, int H, hipStream_t st, int n_windows,
+                           int ldq) {
+    if (ldq == 0) ldq = 2 * d;
+    MW_CHECK(qk && vt && out && n_ctx > 0 && d == H * 64 && tp % FK == 0 && tp >= n_ctx && tp - n_ctx < FK && ldq >= 2 * d && ldq % 8 == 0,
+             "enc_flash_attn: shape");
     const float scale_log2 = (1.0f / sqrtf(64.0f)) * 1.4426950408889634f;
     MW_CHECK(n_windows >= 1 && n_windows <= 65535, "enc_flash_attn: window count");
     hipLaunchKernelGGL(enc_flash_attn_kernel, dim3(ceil_div(n_ctx, FQ), H, n_windows), dim3(256), 0, st, (const bf16_t *)qk, (const bf16_t *)vt,
-                       (bf16_t *)out, n_ctx, tp, d, scale_log2);
+                       (bf16_t *)out, n_ctx, tp, d, scale_log2, ldq);
     MW_HIP(hipGetLastError());
 }
 

@@ -108,7 +108,40 @@ __global__ __launch_bounds__(256) void convert_kernel(const float *__restrict__ 
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) store_out(dst + i, src[i]);
 }
 
+// 64 x 64 tiles through LDS, 16-byte accesses on both sides
+__global__ __launch_bounds__(256) void transpose_v_kernel(const bf16_t *__restrict__ src, long lds_, bf16_t *__restrict__ vt, int n_ctx, int tp,
+                                                          int d) {
+    __shared__ bf16_t tile[64][64 + 8];
+    const int t0 = blockIdx.x * 64, n0 = blockIdx.y * 64, w = blockIdx.z;
+    const int tid = threadIdx.x, r = tid >> 3, c8 = (tid & 7) * 8;
+    src += (long)w * n_ctx * lds_;
+    vt += (long)w * d * tp;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int t = t0 + r + 32 * it;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (t < n_ctx) v = *reinterpret_cast<const uint4 *>(src + (long)t * lds_ + n0 + c8);
+        const bf16_t *e = reinterpret_cast<const bf16_t *>(&v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tile[c8 + k][r + 32 * it] = e[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int n = n0 + r + 32 * it;
+        *reinterpret_cast<uint4 *>(vt + (long)n * tp + t0 + c8) = *reinterpret_cast<const uint4 *>(&tile[r + 32 * it][c8]);
+    }
+}
+
 }  // namespace
+
+void launch_transpose_v(const void *src, long lds_, void *vt, int n_ctx, int tp, int d, int n_windows, hipStream_t st) {
+    MW_CHECK(src && vt && n_ctx > 0 && tp % 64 == 0 && tp >= n_ctx && d % 64 == 0 && lds_ % 8 == 0 && ((uintptr_t)src % 16) == 0 &&
+                 ((uintptr_t)vt % 16) == 0 && n_windows >= 1 && n_windows <= 65535,
+             "transpose_v: shape / alignment");
+    hipLaunchKernelGGL(transpose_v_kernel, dim3(tp / 64, d / 64, n_windows), dim3(256), 0, st, (const bf16_t *)src, lds_, (bf16_t *)vt, n_ctx, tp, d);
+    MW_HIP(hipGetLastError());
+}
 
 void launch_layernorm(const float *x, long ldx, const float *w, const float *b, void *out, long ldo, DType out_t,
                       int rows, int d, hipStream_t st) {

@@ -47,15 +47,19 @@ static MxWorkspace mx_workspace(unsigned char *base, int M_alloc, int d) {
     w.ffs = w.hs + mx_align(mx_scale_bytes_a(M_alloc, d));
     return w;
 }
-// One encoder block's MX-fp8 products (Model::enc_mx) over M rows: x -> LayerNorm (e4m3 + bf16 for V) -> Q|K; and
-// LayerNorm -> fc1 + GELU (e4m3) -> fc2 + residual.  The bf16 path's launches of V, attention and the attention output sit
-// between the two (the callers).
-static void mx_ln_qk(const EncLayer &e, const float *x, void *h_bf16, void *qk, const MxWorkspace &w, int M, int d, hipStream_t s) {
-    launch_layernorm_mx(x, d, e.ln1_w, e.ln1_b, h_bf16, d, w.h8, d, w.hs, M, d, s);
+// One encoder block's MX-fp8 products (Model::enc_mx) over M = windows x n_ctx rows: x -> LayerNorm (e4m3) -> Q|K|V as ONE
+// product with rows of 3 d (the fused attention reads Q | K with that stride), V's columns transposed per window into the
+// layout the attention reads; and LayerNorm -> fc1 + GELU (e4m3) -> fc2 + residual.  The bf16 path's attention and
+// attention-output launches sit between the two (the callers).
+static void mx_ln_qkv(const EncLayer &e, const float *x, void *qkv, void *vt, const MxWorkspace &w, int windows, int n_ctx, int tp, int d,
+                      hipStream_t s) {
+    const int M = windows * n_ctx;
+    launch_layernorm_mx(x, d, e.ln1_w, e.ln1_b, nullptr, d, w.h8, d, w.hs, M, d, s);
     GemmMxArgs g;
-    g.A = w.h8; g.SA = w.hs; g.lda = d; g.W = e.qk_w8; g.SW = e.qk_s8; g.ldw = d; g.C = qk; g.ldc = 2 * d; g.bias = e.qk_b;
-    g.M = M; g.N = 2 * d; g.K = d;
+    g.A = w.h8; g.SA = w.hs; g.lda = d; g.W = e.qk_w8; g.SW = e.qk_s8; g.ldw = d; g.C = qkv; g.ldc = 3 * d; g.bias = e.qk_b;
+    g.M = M; g.N = 3 * d; g.K = d;
     launch_gemm_mx(g, MXE_BF16, s);
+    launch_transpose_v((const bf16_t *)qkv + 2 * d, 3L * d, vt, n_ctx, tp, d, windows, s);
 }
 // ln_post (bf16 rows for the getter + e4m3 rows) and the cross K (scaled by dh^-1/4, no bias) / V (+ bias) of every decoder
 // layer as two batched MX-fp8 launches, into one context's buffers
@@ -145,7 +149,7 @@ std::unique_ptr<Context> create_context_impl(const unsigned char *data, size_t s
     dev_alloc_bytes(c->d_x1, (2 * T + 1) * d * ws);
     dev_alloc(c->d_x, T * d);
     dev_alloc_bytes(c->d_h, T * d * ws);
-    dev_alloc_bytes(c->d_qk, T * 2 * d * ws);
+    dev_alloc_bytes(c->d_qk, T * (c->model.enc_mx ? 3 : 2) * d * ws);  // (MX-fp8 mode: Q | K | V rows)
     dev_alloc_bytes(c->d_vt, d * c->tp * ws);
     dev_alloc(c->d_s, H * T * c->tp);
     dev_alloc_bytes(c->d_p, H * T * c->tp * ws);
@@ -287,7 +291,7 @@ std::shared_ptr<Hub> create_hub(const Model &m, int device, bool use_graphs) {
         dev_alloc_bytes(el.e_x1, W * (2 * T + 1) * da * 2);
         dev_alloc(el.e_x, W * T * da);
         dev_alloc_bytes(el.e_h, W * T * da * 2);
-        dev_alloc_bytes(el.e_qk, W * T * 2 * da * 2);
+        dev_alloc_bytes(el.e_qk, W * T * (m.enc_mx ? 3 : 2) * da * 2);
         dev_alloc_bytes(el.e_vt, W * da * tp * 2);
         dev_alloc_bytes(el.e_att, W * T * da * 2);
         dev_alloc_bytes(el.e_ff, W * T * 4 * da * 2);
@@ -409,7 +413,7 @@ void Hub::run_encode(EncLane &ln, const std::vector<EncRequest *> &batch) {
     for (int l = 0; l < hp.n_audio_layer; ++l) {
         const EncLayer &e = m.enc[l];
         if (m.enc_mx) {
-            mx_ln_qk(e, e_x, e_h, e_qk, mxw, M, d, s);
+            mx_ln_qkv(e, e_x, e_qk, e_vt, mxw, W, n_ctx, tp, d, s);
         } else {
             launch_layernorm(e_x, d, e.ln1_w, e.ln1_b, e_h, d, wt, M, d, s);
             GemmArgs g;  // Q | K of all windows
@@ -417,14 +421,14 @@ void Hub::run_encode(EncLane &ln, const std::vector<EncRequest *> &batch) {
             g.M = M; g.N = 2 * d; g.K = d;
             launch_gemm(g, wt, wt, s);
         }
-        {
+        if (!m.enc_mx) {
             GemmArgs g;  // V, stored transposed [d][tp] per window
             g.A = e_h; g.lda = d; g.W = e.v_w; g.ldw = d; g.C = e_vt; g.ldc = tp; g.bias = e.v_b;
             g.M = n_ctx; g.N = d; g.K = d; g.trans_c = 1;
             g.nz0 = W; g.sA0 = (long)n_ctx * d; g.sC0 = (long)d * tp;
             launch_gemm(g, wt, wt, s);
         }
-        launch_enc_flash_attn(e_qk, e_vt, e_att, n_ctx, tp, d, H, s, W);
+        launch_enc_flash_attn(e_qk, e_vt, e_att, n_ctx, tp, d, H, s, W, m.enc_mx ? 3 * d : 2 * d);
         {
             GemmArgs g;  // x += att Wo^T + bo
             g.A = e_att; g.lda = d; g.W = e.out_w; g.ldw = d; g.C = e_x; g.ldc = d; g.bias = e.out_b;
@@ -875,7 +879,7 @@ void encode(Context &c, int seek) {
     for (int l = 0; l < hp.n_audio_layer; ++l) {
         const EncLayer &e = m.enc[l];
         if (m.enc_mx) {
-            mx_ln_qk(e, c.d_x, c.d_h, c.d_qk, mxw, n_ctx, d, st);
+            mx_ln_qkv(e, c.d_x, c.d_qk, c.d_vt, mxw, 1, n_ctx, tp, d, st);
         } else {
             launch_layernorm(c.d_x, d, e.ln1_w, e.ln1_b, c.d_h, d, wt, n_ctx, d, st);
             GemmArgs g;  // Q | K
@@ -883,18 +887,19 @@ void encode(Context &c, int seek) {
             g.M = n_ctx; g.N = 2 * d; g.K = d;
             gemm(g, wt, wt, st);
         }
-        {
+        if (!m.enc_mx) {
             GemmArgs g;  // V, stored transposed [d][tp]
             g.A = c.d_h; g.lda = d; g.W = e.v_w; g.ldw = d; g.C = c.d_vt; g.ldc = tp; g.bias = e.v_b;
             g.M = n_ctx; g.N = d; g.K = d; g.trans_c = 1;
             gemm(g, wt, wt, st);
         }
         if (c.flash_attn) {
-            launch_enc_flash_attn(c.d_qk, c.d_vt, c.d_att, n_ctx, tp, d, H, st);  // fused: scores never leave the chip
+            launch_enc_flash_attn(c.d_qk, c.d_vt, c.d_att, n_ctx, tp, d, H, st, 1, m.enc_mx ? 3 * d : 2 * d);  // fused: scores never leave the chip
         } else {
             {
                 GemmArgs g;  // S_h = Q_h K_h^T, batched over heads
-                g.A = c.d_qk; g.lda = 2 * d; g.W = (char *)c.d_qk + (size_t)d * ws; g.ldw = 2 * d;
+                const int qk_ld = m.enc_mx ? 3 * d : 2 * d;  // (MX-fp8 mode: rows of Q | K | V)
+                g.A = c.d_qk; g.lda = qk_ld; g.W = (char *)c.d_qk + (size_t)d * ws; g.ldw = qk_ld;
                 g.C = c.d_s; g.ldc = tp; g.M = n_ctx; g.N = n_ctx; g.K = 64;
                 g.nz1 = H; g.sA1 = 64; g.sW1 = 64; g.sC1 = (long)n_ctx * tp;
                 gemm(g, wt, DType::F32, st);

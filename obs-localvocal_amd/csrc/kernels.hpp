@@ -129,8 +129,12 @@ void launch_layernorm(const float *x, long ldx, const float *w, const float *b, 
 // fused encoder self-attention, bf16: qk = [n_ctx][2d] (Q | K), vt = V transposed [d][tp] (pad columns finite),
 // out = [n_ctx][d]; heads of 64
 // n_windows > 1: the windows of a batched encoder pass, slabs back to back (qk [w][n_ctx][2d], vt [w][d][tp], out [w][n_ctx][d])
+// ldq: row stride of qk in elements (0: 2 d)
 void launch_enc_flash_attn(const void *qk, const void *vt, void *out, int n_ctx, int tp, int d, int H, hipStream_t st,
-                           int n_windows = 1);
+                           int n_windows = 1, int ldq = 0);
+// vt[w][n][t] = src[(w n_ctx + t) lds + n] for t < n_ctx, 0 for n_ctx <= t < tp  (bf16; the V columns of a Q|K|V product ->
+// the transposed per-window layout the fused attention reads); d % 64 == 0, tp % 64 == 0
+void launch_transpose_v(const void *src, long lds_, void *vt, int n_ctx, int tp, int d, int n_windows, hipStream_t st);
 void launch_softmax_rows(const float *s, long lds_, void *out, long ldo, DType out_t, long rows, int n, int n_pad,
                          float scale, hipStream_t st);
 void launch_fill_zero(void *p, size_t bytes, hipStream_t st);

@@ -427,7 +427,7 @@ void load_model(Model &m, const unsigned char *data, size_t size, DType wt, hipS
     m.enc_mx = fp8 >= 2;
     if (m.enc_mx && d % 256 != 0) throw std::runtime_error("MX-fp8 encoder: n_audio_state must be a multiple of 256");
     if (m.enc_mx)  // Q|K (2 d^2), fc1 and fc2 (8 d^2) as bytes + one scale byte per 32
-        m.arena_size += Le * (10 * d * d + 10 * d * d / 32 + 6 * 256) + Ld * (2 * d * d + 2 * d * d / 32) + 2 * 256;
+        m.arena_size += Le * (11 * d * d + 11 * d * d / 32 + 6 * 256) + Ld * (2 * d * d + 2 * d * d / 32) + 2 * 256;
     MW_HIP(hipMalloc((void **)&m.arena, m.arena_size));
     m.arena_owner = std::shared_ptr<void>(m.arena, free_device_block);
     L.staging_size = max_bytes;
@@ -444,13 +444,15 @@ void load_model(Model &m, const unsigned char *data, size_t size, DType wt, hipS
             EncLayer &e = m.enc[i];
             e.ln1_w = L.vec(p + "attn_ln.weight", d);
             e.ln1_b = L.vec(p + "attn_ln.bias", d);
-            e.qk_w = L.alloc(2 * d * d * ws);
+            e.qk_w = L.alloc(3 * d * d * ws);  // Q | K | V rows, contiguous: the bf16 path reads [2d][d] + [d][d], MX-fp8 all [3d][d]
             L.put(p + "attn.query.weight", d * d, e.qk_w, wt);
             L.put(p + "attn.key.weight", d * d, (char *)e.qk_w + d * d * ws, wt);
-            e.qk_b = L.zeros(2 * d);
+            e.v_w = (char *)e.qk_w + 2 * d * d * ws;
+            L.put(p + "attn.value.weight", d * d, e.v_w, wt);
+            e.qk_b = L.zeros(3 * d);
             L.put(p + "attn.query.bias", d, e.qk_b, DType::F32);
-            e.v_w = L.mat(p + "attn.value.weight", d * d);
-            e.v_b = L.vec(p + "attn.value.bias", d);
+            e.v_b = e.qk_b + 2 * d;
+            L.put(p + "attn.value.bias", d, e.v_b, DType::F32);
             e.out_w = L.mat(p + "attn.out.weight", d * d);
             e.out_b = L.vec(p + "attn.out.bias", d);
             e.ln2_w = L.vec(p + "mlp_ln.weight", d);
@@ -460,7 +462,7 @@ void load_model(Model &m, const unsigned char *data, size_t size, DType wt, hipS
             e.fc2_w = L.mat(p + "mlp.2.weight", 4 * d * d);
             e.fc2_b = L.vec(p + "mlp.2.bias", d);
             if (m.enc_mx) {
-                L.quantize_mx(e.qk_w, 2 * d, d, e.qk_w8, e.qk_s8);
+                L.quantize_mx(e.qk_w, 3 * d, d, e.qk_w8, e.qk_s8);  // Q | K | V
                 L.quantize_mx(e.fc1_w, 4 * d, d, e.fc1_w8, e.fc1_s8);
                 L.quantize_mx(e.fc2_w, d, 4 * d, e.fc2_w8, e.fc2_s8);
             }

@@ -559,7 +559,7 @@ void encode(ow_context &c, int mel_offset) {
     std::vector<float> h((size_t)n_ctx * d), q((size_t)n_ctx * d), k((size_t)n_ctx * d), v((size_t)n_ctx * d),
         att((size_t)n_ctx * d), tmp((size_t)n_ctx * d), ff((size_t)n_ctx * 4 * d);
     const float kq_scale = 1.0f / sqrtf((float)dh);
-    // MX twin: weights and the activation operand of the Q, K, fc1, fc2 products on the MX-fp8 grid; V reads h as it is
+    // MX twin: weights and the activation operand of the Q, K, V, fc1, fc2 (and cross K / V) products on the MX-fp8 grid
     auto mxw = [&](const std::string &name, int K) -> const float * {
         if (!c.mx_encoder) return m.get(name).data();
         auto it = c.mx_weights.find(name);
@@ -580,8 +580,7 @@ void encode(ow_context &c, int mel_offset) {
         }
         matmul_nt(q.data(), d, hq, d, mxw(p + "attn.query.weight", d), d, m.get(p + "attn.query.bias").data(), n_ctx, d, d);
         matmul_nt(k.data(), d, hq, d, mxw(p + "attn.key.weight", d), d, nullptr, n_ctx, d, d);
-        matmul_nt(v.data(), d, h.data(), d, m.get(p + "attn.value.weight").data(), d, m.get(p + "attn.value.bias").data(),
-                  n_ctx, d, d);
+        matmul_nt(v.data(), d, hq, d, mxw(p + "attn.value.weight", d), d, m.get(p + "attn.value.bias").data(), n_ctx, d, d);
 #pragma omp parallel
         {
             std::vector<float> s(n_ctx);

@@ -1,4 +1,4 @@
-"""GPU: MW_PRECISION_FP8_MX — the encoder's Q|K, fc1 and fc2 products in MX-fp8 on the fp8 matrix cores (gemm_mx.hip).
+"""GPU: MW_PRECISION_FP8_MX — the encoder's Q|K|V, fc1 and fc2 products (and the cross K / V projections) in MX-fp8 on the fp8 matrix cores (gemm_mx.hip).
 
 The arithmetic the mode declares is restated in the oracle (oracle/whisper_oracle.cpp: mx_qdq_rows, ow_set_mx_encoder):
 per block of 32 along k the smallest power-of-two scale that brings the block under 448, e4m3 elements rounded to nearest
@@ -10,7 +10,7 @@ even; products and everything else in fp32.  Parity is therefore checked at thre
     PROD_TOL of sum |a w|, for every tile height the launcher chooses and a ragged last tile;
   * the whole encoder (and teacher-forced decoder steps on its cross K / V) at large-v3 dims against the fp32 oracle AND
     the oracle's MX twin.  An e4m3 element changes by 6-12 % when its input crosses a rounding boundary, and the engine's
-    inputs differ from the twin's by the bf16 rounding of everything that stays bf16 (conv stem, V, attention): a few per
+    inputs differ from the twin's by the bf16 rounding of everything that stays bf16 (conv stem, attention, attention output): a few per
     cent of the elements of every block round the other way, so after 32 blocks engine and twin are two realisations of
     the same quantisation noise rather than equal numbers (measured: engine - twin 0.055, engine - fp32 0.047, twin - fp32
     0.047 of the largest activation).  What the test asserts is therefore: the engine is no further from the fp32 oracle
@@ -136,7 +136,7 @@ def test_encoder_and_teacher_forced_steps_against_the_oracles_mx_twin(pkg, mx_mo
         rel_twin = float(np.abs(got - twin).max() / np.abs(twin).max())
         rel_plain = float(np.abs(got - plain).max() / np.abs(plain).max())
         cost = float(np.abs(twin - plain).max() / np.abs(plain).max())
-        print(f"encoder, 32 blocks, MX-fp8 Q|K / fc1 / fc2: engine vs the oracle's MX twin {rel_twin:.4f}; engine vs fp32 oracle {rel_plain:.4f}; "
+        print(f"encoder, 32 blocks, MX-fp8 Q|K|V / fc1 / fc2: engine vs the oracle's MX twin {rel_twin:.4f}; engine vs fp32 oracle {rel_plain:.4f}; "
               f"twin vs fp32 oracle (the format's own cost) {cost:.4f}   (max |d| / max |ref|)")
         assert rel_plain < MX_COST_TOL
         assert rel_plain <= 1.25 * cost + ENC_TOL / 4      # as close to the truth as the declared arithmetic
