@@ -205,3 +205,45 @@ def test_a_window_encodes_to_the_same_bits_alone_and_inside_a_batched_pass(pkg, 
     finally:
         for e in engs[1:] + engs[:1]:
             e.close()
+
+
+def test_base_dims_shorter_audio_context_and_a_model_the_mode_does_not_fit(pkg, tmp_path):
+    """d = 512 (base.en: two 256-column tiles, 4 k-steps, 80 mel bins), the full and a shorter audio context (n_ctx = 500: the
+    last 16-row slice, the 64-column pad of V^T and the scale records of a ragged 128-row block), against the fp32 oracle
+    and its MX twin; tiny.en (d = 384, not a multiple of 256) is refused at load with a message, not computed some other way."""
+    path = str(tmp_path / "base-mx.bin")
+    synth_large.write_large(path, "base.en", seed=77, quiet_special=True, fp8_decoder=True, mx_encoder=True)
+    pcm = ggml_io.synth_pcm(5, 30.0)
+    orc = pyoracle.Oracle(path)
+    eng = pkg.Engine(path, precision=pkg.PRECISION_FP8_MX)
+    try:
+        orc.mel(pcm)
+        eng.mel(pcm)
+        for audio_ctx in (0, 500):
+            orc.set_mx_encoder(False)
+            plain = orc.encode(0, audio_ctx)
+            k_plain = orc.cross_kv(0, False, audio_ctx or None)
+            orc.set_mx_encoder(True)
+            twin = orc.encode(0, audio_ctx)
+            got = eng.encode(0, audio_ctx)
+            assert got.shape == twin.shape and np.isfinite(got).all()
+            cost = float(np.abs(twin - plain).max() / np.abs(plain).max())
+            rel_plain = float(np.abs(got - plain).max() / np.abs(plain).max())
+            rel_twin = float(np.abs(got - twin).max() / np.abs(twin).max())
+            print(f"base.en dims, audio_ctx {audio_ctx or 1500}: engine vs twin {rel_twin:.4f}, engine vs fp32 oracle {rel_plain:.4f}, twin vs fp32 oracle {cost:.4f}")
+            assert rel_plain <= 1.25 * cost + ENC_TOL / 4 and rel_twin <= 1.5 * cost + ENC_TOL / 4
+            k_eng, k_orc = eng.cross_kv(0, False, audio_ctx or None), orc.cross_kv(0, False, audio_ctx or None)
+            assert k_eng.shape == k_orc.shape
+            cost_k = float(np.abs(k_orc - k_plain).max() / np.abs(k_plain).max())   # the cross K product quantises once more
+            assert float(np.abs(k_eng - k_orc).max() / np.abs(k_orc).max()) <= 1.5 * cost_k + ENC_TOL
+            assert float(np.abs(k_eng - k_plain).max() / np.abs(k_plain).max()) <= 1.25 * cost_k + ENC_TOL
+    finally:
+        eng.close()
+        orc.close()
+    tiny = str(tmp_path / "tiny-mx.bin")
+    synth_large.write_large(tiny, "tiny.en", seed=78, quiet_special=True)
+    with pytest.raises(Exception) as ei:
+        pkg.Engine(tiny, precision=pkg.PRECISION_FP8_MX)
+    assert "256" in str(ei.value) or "MX" in str(ei.value), str(ei.value)
+    ok = pkg.Engine(tiny, precision=pkg.PRECISION_FP8)     # the e4m3-decoder mode has no such limit
+    ok.close()
