@@ -247,8 +247,8 @@ struct ow_context {
     int lang_id = 0;
     int n_decode_calls = 0, n_encode_calls = 0;
     std::string tmp_str;
-    // MX-fp8 twin of the engine's MW_PRECISION_FP8_MX encoder (ow_set_mx_encoder): the operands of the Q, K, fc1 and fc2
-    // products of every encoder block pass through mx_qdq_rows first (weights once, cached here)
+    // MX-fp8 twin of the engine's MW_PRECISION_FP8_MX encoder (ow_set_mx_encoder): the operands of the Q, K, V, fc1 and fc2
+    // products of every encoder block and of the cross K / V projections pass through mx_qdq_rows first (weights once, cached here)
     bool mx_encoder = false;
     std::map<std::string, std::vector<float>> mx_weights;
 };
