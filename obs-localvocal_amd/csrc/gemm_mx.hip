@@ -450,8 +450,19 @@ void launch_gemm_mx(const GemmMxArgs &args, int epi, hipStream_t st) {
     // the largest tile height that still gives the 256 CUs about a tile each (M = 1500: 64 or 128 rows; batched passes: 256)
     MW_CHECK(a.nz >= 1 && (a.nz == 1 || (epi == MXE_BF16 && a.sW % 16 == 0 && a.sSW % 4 == 0 && a.sC % 8 == 0 && a.sBias % 4 == 0)),
              "gemm (mx): batch strides (bf16 rows only)");
+    // Tile height: the one with the shortest estimated launch, rounds of <= 256 resident tiles x (k-steps x time of a k-step +
+    // epilogue), with the k-step and epilogue times measured per height (us; mb_gemm_mx): M = 1500 runs fc2 on 64-row tiles
+    // (120 of them), fc1 and Q|K|V on 128-row tiles (240 / 180: one round), batched passes on 256-row tiles.  Any choice
+    // gives the same bits.
     const long nt = (long)(a.N / 256) * a.nz;
-    const int bm = nt * ceil_div(a.M, 256) >= 200 ? 256 : nt * ceil_div(a.M, 128) >= 200 ? 128 : 64;
+    const int nk = a.K / 128;
+    int bm = 256;
+    double best = 1e30;
+    for (int cand : {256, 128, 64}) {
+        const double t_k = cand == 256 ? 1.9 : cand == 128 ? 1.3 : 1.0, t_e = cand == 256 ? 6.0 : cand == 128 ? 4.0 : 2.5;
+        const double cost = (double)ceil_div<long>(nt * ceil_div(a.M, cand), 256) * (nk * t_k + t_e);
+        if (cost < best - 1e-9) best = cost, bm = cand;
+    }
     const long tiles = nt * ceil_div(a.M, bm);
     MW_CHECK(tiles < (1L << 28), "gemm (mx): tile count");
     const dim3 pgrid((unsigned)std::min<long>(ceil_div<long>(tiles, 8) * 8, 256));
