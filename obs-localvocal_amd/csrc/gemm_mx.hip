@@ -135,6 +135,125 @@ __global__ __launch_bounds__(256) void layernorm_mx_kernel(const float *__restri
     }
 }
 
+constexpr int MX_EPI_PATCH = 16 * (64 + 4) * 4 + 256;  // bytes of LDS a wave uses in the epilogue
+
+// The epilogue of one output tile, shared by the two MX GEMM kernels below: the accumulators of a wave (RT row tiles of
+// 16 x 64) take a turn through the wave's own LDS patch `stg` so that a lane stores whole 16- or 32-byte runs of a row.
+template <int EPI, int BM>
+__device__ __forceinline__ void mx_tile_epilogue(const GemmMxArgs &a, f32x4 (&acc)[BM / 32][4], float *stg, int m0, int n0, int z0, int lane,
+                                                 int wr, int wc, int M, int MB) {
+    constexpr int RT = BM / 32, SROW = 64 + 4;
+    const int ncol0 = n0 + wc * 64;
+    const float *bias_z = a.bias ? a.bias + z0 * a.sBias : nullptr;
+    const long c_off = z0 * a.sC;  // elements of the output type
+    auto epilogue = [&](auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        if constexpr (EPI == MXE_F32_RES) {
+            // (the row predicate stays on these stores on purpose: gemm.hip, fp32 epilogue)
+            float *C = reinterpret_cast<float *>(a.C) + c_off;
+            const int erow = lane >> 4, ecol = 4 * (lane & 15), nb = ncol0 + ecol;
+            const float4 b4 = *reinterpret_cast<const float4 *>(bias_z ? bias_z + nb : a.epi_zero);
+#pragma unroll
+            for (int i8 = 0; i8 < RT; ++i8) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 v = acc[i8][j];
+                    v *= a.alpha;
+                    *reinterpret_cast<f32x4 *>(stg + (lane & 15) * SROW + 16 * j + 4 * (lane >> 4)) = v;
+                }
+                const int mrow0 = m0 + wr * (BM / 2) + i8 * 16;
+                float4 rv[4];
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int m = min(mrow0 + erow + 4 * it, M - 1);
+                    rv[it] = *reinterpret_cast<const float4 *>(a.R + (long)m * a.ldr + nb);
+                }
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int mr = mrow0 + erow + 4 * it;
+                    const f32x4 t = *reinterpret_cast<const f32x4 *>(stg + (erow + 4 * it) * SROW + ecol);
+                    const float4 o = make_float4(t[0] + b4.x + rv[it].x, t[1] + b4.y + rv[it].y, t[2] + b4.z + rv[it].z,
+                                                 t[3] + b4.w + rv[it].w);
+                    if (mr < M) *reinterpret_cast<float4 *>(C + (long)mr * a.ldc + nb) = o;
+                }
+            }
+        } else {
+            // a lane takes 8 columns of a row, 8 lanes one row's 64 columns, 8 rows per instruction
+            const int erow = lane >> 3, ecol = 8 * (lane & 7), nb = ncol0 + ecol;
+            const float *bp = bias_z ? bias_z + nb : a.epi_zero;
+            const float4 b0 = *reinterpret_cast<const float4 *>(bp), b1 = *reinterpret_cast<const float4 *>(bias_z ? bp + 4 : bp);
+            const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            unsigned long long scl[2] = {0ull, 0ull};  // MXE_MX_GELU: the scale bytes of rows erow, erow + 8 of the RT slices
+#pragma unroll
+            for (int i8 = 0; i8 < RT; ++i8) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 v = acc[i8][j];
+                    v *= a.alpha;
+                    *reinterpret_cast<f32x4 *>(stg + (lane & 15) * SROW + 16 * j + 4 * (lane >> 4)) = v;
+                }
+                const int mrow0 = m0 + wr * (BM / 2) + i8 * 16;
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int mr = mrow0 + erow + 8 * it;
+                    const f32x4 t0 = *reinterpret_cast<const f32x4 *>(stg + (erow + 8 * it) * SROW + ecol);
+                    const f32x4 t1 = *reinterpret_cast<const f32x4 *>(stg + (erow + 8 * it) * SROW + ecol + 4);
+                    float x[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        x[r] += bb[r];
+                        if constexpr (EPI == MXE_MX_GELU) x[r] = gelu_mx(x[r]);
+                    }
+                    if constexpr (EPI == MXE_BF16) {
+                        bf16_t *C = reinterpret_cast<bf16_t *>(a.C) + c_off;
+                        unsigned pk[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            __hip_bfloat16 h0 = __float2bfloat16(x[2 * r]), h1 = __float2bfloat16(x[2 * r + 1]);
+                            pk[r] = (unsigned)*reinterpret_cast<bf16_t *>(&h0) | ((unsigned)*reinterpret_cast<bf16_t *>(&h1) << 16);
+                        }
+                        using u32x4n = __attribute__((ext_vector_type(4))) unsigned;
+                        const u32x4n out4 = {pk[0], pk[1], pk[2], pk[3]};
+                        if (FULL || mr < M) __builtin_nontemporal_store(out4, reinterpret_cast<u32x4n *>(C + (long)mr * a.ldc + nb));
+                    } else {
+                        // block of 32 output columns = lanes 4 b .. 4 b + 3 of the row's 8: absmax over the quad, one scale
+                        float amax = 0.0f;
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) amax = fmaxf(amax, fabsf(x[r]));
+                        amax = fmaxf(amax, __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(amax), 0xB1, 0xf, 0xf, false)));
+                        amax = fmaxf(amax, __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(amax), 0x4E, 0xf, 0xf, false)));
+                        const unsigned sb = mx_scale_byte(amax);
+                        const float inv = mx_inv_scale(sb);
+                        using u32x2n = __attribute__((ext_vector_type(2))) unsigned;
+                        const u32x2n out2 = {pack4_e4m3(x[0] * inv, x[1] * inv, x[2] * inv, x[3] * inv),
+                                             pack4_e4m3(x[4] * inv, x[5] * inv, x[6] * inv, x[7] * inv)};
+                        unsigned char *C = reinterpret_cast<unsigned char *>(a.C);
+                        if (FULL || mr < M) __builtin_nontemporal_store(out2, reinterpret_cast<u32x2n *>(C + (long)mr * a.ldc + nb));
+                        scl[it] |= (unsigned long long)sb << (8 * i8);
+                    }
+                }
+            }
+            if constexpr (EPI == MXE_MX_GELU) {
+                // one 8-byte record per (128-row block, row & 15, output k-block), of which this wave's RT row tiles are
+                // bytes base .. base + RT - 1: lane (erow, quad leader) holds rows erow and erow + 8
+                if ((lane & 3) == 0) {
+                    const int kb = (ncol0 >> 5) + ((lane & 7) >> 2);  // block of 32 output columns
+                    const int mw = m0 + wr * (BM / 2), mblk = mw >> 7, base = (mw >> 4) & 7;
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) {
+                        unsigned char *rec = a.SC + (((size_t)(kb >> 2) * MB + mblk) * 64 + ((kb & 3) * 16 + erow + 8 * it)) * 8 + base;
+                        if constexpr (RT == 8) *reinterpret_cast<unsigned long long *>(rec) = scl[it];
+                        else if constexpr (RT == 4) *reinterpret_cast<unsigned *>(rec) = (unsigned)scl[it];
+                        else *reinterpret_cast<unsigned short *>(rec) = (unsigned short)scl[it];
+                    }
+                }
+            }
+        }
+    };
+    if (m0 + BM <= M) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // 256 x 256 persistent MX-fp8 GEMM.  Structure, staging, tile order and the LDS turn of the epilogue are those of
 // gemm_bf16_256_kernel (gemm.hip; its comments give the measurements behind them): 8 waves as 2 (M) x 4 (N), each 128 x 64
@@ -275,124 +394,150 @@ __global__ __launch_bounds__(512) void gemm_mxfp8_256_kernel(GemmMxArgs a) {
             par ^= 1;
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave has read the last k-step
-        {
-            constexpr int SROW = 64 + 4;
-            float *stg = reinterpret_cast<float *>(lds + (par ^ 1) * STAGE + wave * (16 * SROW * 4 + 256));
-            const int ncol0 = n0 + wc * 64;
-            const float *bias_z = a.bias ? a.bias + z0 * a.sBias : nullptr;
-            const long c_off = z0 * a.sC;  // elements of the output type
-            auto epilogue = [&](auto full_tag) {
-                constexpr bool FULL = decltype(full_tag)::value;
-                if constexpr (EPI == MXE_F32_RES) {
-                    // (the row predicate stays on these stores on purpose: gemm.hip, fp32 epilogue)
-                    float *C = reinterpret_cast<float *>(a.C) + c_off;
-                    const int erow = lane >> 4, ecol = 4 * (lane & 15), nb = ncol0 + ecol;
-                    const float4 b4 = *reinterpret_cast<const float4 *>(bias_z ? bias_z + nb : a.epi_zero);
-#pragma unroll
-                    for (int i8 = 0; i8 < RT; ++i8) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            f32x4 v = acc[i8][j];
-                            v *= a.alpha;
-                            *reinterpret_cast<f32x4 *>(stg + (lane & 15) * SROW + 16 * j + 4 * (lane >> 4)) = v;
-                        }
-                        const int mrow0 = m0 + wr * (BM / 2) + i8 * 16;
-                        float4 rv[4];
-#pragma unroll
-                        for (int it = 0; it < 4; ++it) {
-                            const int m = min(mrow0 + erow + 4 * it, M - 1);
-                            rv[it] = *reinterpret_cast<const float4 *>(a.R + (long)m * a.ldr + nb);
-                        }
-#pragma unroll
-                        for (int it = 0; it < 4; ++it) {
-                            const int mr = mrow0 + erow + 4 * it;
-                            const f32x4 t = *reinterpret_cast<const f32x4 *>(stg + (erow + 4 * it) * SROW + ecol);
-                            const float4 o = make_float4(t[0] + b4.x + rv[it].x, t[1] + b4.y + rv[it].y, t[2] + b4.z + rv[it].z,
-                                                         t[3] + b4.w + rv[it].w);
-                            if (mr < M) *reinterpret_cast<float4 *>(C + (long)mr * a.ldc + nb) = o;
-                        }
-                    }
-                } else {
-                    // a lane takes 8 columns of a row, 8 lanes one row's 64 columns, 8 rows per instruction
-                    const int erow = lane >> 3, ecol = 8 * (lane & 7), nb = ncol0 + ecol;
-                    const float *bp = bias_z ? bias_z + nb : a.epi_zero;
-                    const float4 b0 = *reinterpret_cast<const float4 *>(bp), b1 = *reinterpret_cast<const float4 *>(bias_z ? bp + 4 : bp);
-                    const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-                    unsigned long long scl[2] = {0ull, 0ull};  // MXE_MX_GELU: the scale bytes of rows erow, erow + 8 of the RT slices
-#pragma unroll
-                    for (int i8 = 0; i8 < RT; ++i8) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            f32x4 v = acc[i8][j];
-                            v *= a.alpha;
-                            *reinterpret_cast<f32x4 *>(stg + (lane & 15) * SROW + 16 * j + 4 * (lane >> 4)) = v;
-                        }
-                        const int mrow0 = m0 + wr * (BM / 2) + i8 * 16;
-#pragma unroll
-                        for (int it = 0; it < 2; ++it) {
-                            const int mr = mrow0 + erow + 8 * it;
-                            const f32x4 t0 = *reinterpret_cast<const f32x4 *>(stg + (erow + 8 * it) * SROW + ecol);
-                            const f32x4 t1 = *reinterpret_cast<const f32x4 *>(stg + (erow + 8 * it) * SROW + ecol + 4);
-                            float x[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
-#pragma unroll
-                            for (int r = 0; r < 8; ++r) {
-                                x[r] += bb[r];
-                                if constexpr (EPI == MXE_MX_GELU) x[r] = gelu_mx(x[r]);
-                            }
-                            if constexpr (EPI == MXE_BF16) {
-                                bf16_t *C = reinterpret_cast<bf16_t *>(a.C) + c_off;
-                                unsigned pk[4];
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) {
-                                    __hip_bfloat16 h0 = __float2bfloat16(x[2 * r]), h1 = __float2bfloat16(x[2 * r + 1]);
-                                    pk[r] = (unsigned)*reinterpret_cast<bf16_t *>(&h0) | ((unsigned)*reinterpret_cast<bf16_t *>(&h1) << 16);
-                                }
-                                using u32x4n = __attribute__((ext_vector_type(4))) unsigned;
-                                const u32x4n out4 = {pk[0], pk[1], pk[2], pk[3]};
-                                if (FULL || mr < M) __builtin_nontemporal_store(out4, reinterpret_cast<u32x4n *>(C + (long)mr * a.ldc + nb));
-                            } else {
-                                // block of 32 output columns = lanes 4 b .. 4 b + 3 of the row's 8: absmax over the quad, one scale
-                                float amax = 0.0f;
-#pragma unroll
-                                for (int r = 0; r < 8; ++r) amax = fmaxf(amax, fabsf(x[r]));
-                                amax = fmaxf(amax, __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(amax), 0xB1, 0xf, 0xf, false)));
-                                amax = fmaxf(amax, __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(amax), 0x4E, 0xf, 0xf, false)));
-                                const unsigned sb = mx_scale_byte(amax);
-                                const float inv = mx_inv_scale(sb);
-                                using u32x2n = __attribute__((ext_vector_type(2))) unsigned;
-                                const u32x2n out2 = {pack4_e4m3(x[0] * inv, x[1] * inv, x[2] * inv, x[3] * inv),
-                                                     pack4_e4m3(x[4] * inv, x[5] * inv, x[6] * inv, x[7] * inv)};
-                                unsigned char *C = reinterpret_cast<unsigned char *>(a.C);
-                                if (FULL || mr < M) __builtin_nontemporal_store(out2, reinterpret_cast<u32x2n *>(C + (long)mr * a.ldc + nb));
-                                scl[it] |= (unsigned long long)sb << (8 * i8);
-                            }
-                        }
-                    }
-                    if constexpr (EPI == MXE_MX_GELU) {
-                        // one 8-byte record per (128-row block, row & 15, output k-block), of which this wave's RT row tiles are
-                        // bytes base .. base + RT - 1: lane (erow, quad leader) holds rows erow and erow + 8
-                        if ((lane & 3) == 0) {
-                            const int kb = (ncol0 >> 5) + ((lane & 7) >> 2);  // block of 32 output columns
-                            const int mw = m0 + wr * (BM / 2), mblk = mw >> 7, base = (mw >> 4) & 7;
-#pragma unroll
-                            for (int it = 0; it < 2; ++it) {
-                                unsigned char *rec = a.SC + (((size_t)(kb >> 2) * MB + mblk) * 64 + ((kb & 3) * 16 + erow + 8 * it)) * 8 + base;
-                                if constexpr (RT == 8) *reinterpret_cast<unsigned long long *>(rec) = scl[it];
-                                else if constexpr (RT == 4) *reinterpret_cast<unsigned *>(rec) = (unsigned)scl[it];
-                                else *reinterpret_cast<unsigned short *>(rec) = (unsigned short)scl[it];
-                            }
-                        }
-                    }
-                }
-            };
-            if (m0 + BM <= M) epilogue(std::true_type{});
-            else epilogue(std::false_type{});
-        }
+        mx_tile_epilogue<EPI, BM>(a, acc, reinterpret_cast<float *>(lds + (par ^ 1) * STAGE + wave * MX_EPI_PATCH), m0, n0, z0, lane, wr, wc, M, MB);
         m0 = m1;
         n0 = n1;
         z0 = z1;
         have = have_next;
         ++round;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same product for few rows and a long K (fc2 of one or two windows, BM = 64), where a workgroup has one tile and its
+// time is the latency of its own k-steps: THREE k-step buffers, each step's loads issued two steps ahead, and the wait at
+// the top of a step counted (`vmcnt(NL)`: the step after this one may still be in flight).  For the count to be the
+// kernel's own, no load of the k-loop has a register destination (hipcc waits for every load in flight where a loaded
+// register is first used): the block scales of a step travel through LDS like the tiles, one more 16-byte DMA per lane —
+// the 512 bytes of the tile's 128-row block of A and the 1 KB of its four 64-row blocks of W, contiguous in the scale
+// layouts — and are read from there at the top of the step.  Tile order, fragment reads, the chain of MFMAs of an output
+// element and the epilogue are those of gemm_mxfp8_256_kernel: same bits.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int EPI, int BM>
+__global__ __launch_bounds__(512) void gemm_mxfp8_s3_kernel(GemmMxArgs a) {
+    static_assert(BM == 128 || BM == 64, "the three-buffer kernel is for the small tiles");
+    constexpr int BK = 128, RB = 128, HALF = 128 * RB, ATILE = BM * RB, SCL = 2048, STAGE = ATILE + 2 * HALF + SCL, NST = 3;
+    constexpr int RT = BM / 32, AP = BM / 64, NL = AP + 4 + 1;  // DMA instructions per wave and k-step
+    static_assert(8 * MX_EPI_PATCH <= STAGE, "the epilogue's patches fit one buffer");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[NST * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 2, wc = wave & 3;
+    const unsigned char *A = a.A, *W = a.W;
+    const int M = a.M, N = a.N, K = a.K;
+    const int tiles_n = N / 256, tiles_m = (M + BM - 1) / BM, tiles_z = tiles_m * tiles_n, ntiles = tiles_z * a.nz, per_xcd = (ntiles + 7) / 8;
+    const int MB = 2 * ((M + 255) / 256), NB = N / 64;
+    auto swz8 = [](int r, int c) { return r * RB + ((c ^ (r & 7)) << 4); };
+    auto tile_of = [&](int r, int &m0, int &n0, int &z) -> bool {
+        const int L = blockIdx.x + r * gridDim.x, j = L >> 3, p = (L & 7) * per_xcd + j;
+        if (j >= per_xcd || p >= ntiles) return false;
+        z = p / tiles_z;
+        const int q = p - z * tiles_z;
+        m0 = (q / tiles_n) * BM;
+        n0 = (q % tiles_n) * 256;
+        return true;
+    };
+    // the loads run two k-steps ahead of the products, across tile ends: they have a cursor (tile round, k-step) of their own
+    const unsigned char *ga[AP], *gw[4], *gs = nullptr;
+    // a step's scale area, 16 bytes per lane: even waves bring A's 512 bytes and the first half of W's 1 KB, odd waves the
+    // second half of W's and a repeat into the padding (every wave issues the same count; the four copies are the same bytes)
+    const bool s_of_a = !(wave & 1) && lane < 32;
+    const long gs_step = s_of_a ? (long)MB * 512 : (long)NB * 256;  // bytes from one k-step's scales to the next
+    const unsigned char *const gs0 = s_of_a ? a.SA + lane * 16 : a.SW + (!(wave & 1) ? (lane - 32) * 16 : lane < 32 ? 512 + lane * 16 : (lane - 32) * 16);
+    auto point = [&](int m0, int n0, int z) {
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) {
+            const int row = 8 * wave + 64 * pc + (lane >> 3), chk = (lane & 7) ^ (row & 7);
+            if (pc < AP) ga[pc] = A + (long)min(m0 + row, M - 1) * a.lda + chk * 16;
+            gw[pc] = W + z * a.sW + (long)min(n0 + row, N - 1) * a.ldw + chk * 16;
+        }
+        gs = gs0 + (s_of_a ? (long)(m0 >> 7) * 512 : z * a.sSW + (long)(n0 >> 6) * 256);
+    };
+    const int nk = K / BK;
+    using gptr_t = const __attribute__((address_space(1))) void *;
+    using lptr_t = __attribute__((address_space(3))) void *;
+    auto issue = [&](int kt, int stage) {
+        const long off = (long)kt * BK;
+        unsigned char *sb = lds + stage * STAGE;
+        unsigned char *sa = sb + (8 * wave) * RB, *sw = sb + ATILE + (8 * wave) * RB;  // wave-uniform
+#pragma unroll
+        for (int pc = 0; pc < AP; ++pc) __builtin_amdgcn_global_load_lds((gptr_t)(ga[pc] + off), (lptr_t)(sa + 64 * pc * RB), 16, 0, 0);
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) __builtin_amdgcn_global_load_lds((gptr_t)(gw[pc] + off), (lptr_t)(sw + 64 * pc * RB), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(gs + kt * gs_step), (lptr_t)(sb + ATILE + 2 * HALF + (wave & 1) * 1024), 16, 0, 0);
+    };
+    int c_round = 0, c_kt = 0, cm = 0, cn = 0, cz = 0;
+    bool c_have = tile_of(0, cm, cn, cz);  // workgroup-uniform throughout
+    if (c_have) point(cm, cn, cz);
+    auto issue_next = [&](int stage) -> bool {
+        if (!c_have) return false;
+        issue(c_kt, stage);
+        if (++c_kt == nk) {
+            c_kt = 0;
+            c_have = tile_of(++c_round, cm, cn, cz);
+            if (c_have) point(cm, cn, cz);
+        }
+        return true;
+    };
+    const int fr = lane & 15, fq = lane >> 4;
+    int m0 = 0, n0 = 0, z0 = 0, round = 0;
+    bool have = tile_of(0, m0, n0, z0);
+    int inflight = 0, si = 0, sc = 0;  // k-steps issued and not yet multiplied; the buffers of the next issue and the next products
+    for (; si < 2; ++si)
+        if (issue_next(si)) ++inflight;
+    while (have) {
+        f32x4 acc[RT][4];
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+        const int sa_shift = 8 * (((m0 + wr * (BM / 2)) >> 4) & 7);  // the wave's RT bytes in the record of its 128-row block (bits)
+        for (int kt = 0; kt < nk; ++kt) {
+            if (inflight >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");  // this step has landed; the next may be on its way
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // ... for every wave's part of it, and every wave is past the step before
+            if (issue_next(si)) {          // into the buffer of the step before
+                ++inflight;
+                si = si == NST - 1 ? 0 : si + 1;
+            }
+            const unsigned char *sb = lds + sc * STAGE;
+            const unsigned char *la = sb + wr * (ATILE / 2), *lw = sb + ATILE + (wc >> 1) * HALF, *ls = sb + ATILE + 2 * HALF;
+            const int wcol = (wc & 1) * 64;
+            typedef int i32x2 __attribute__((ext_vector_type(2)));
+            typedef int i32x1 __attribute__((ext_vector_type(1)));
+            const i32x2 sa2 = *reinterpret_cast<const i32x2 *>(ls + lane * 8);
+            const int sw = (*reinterpret_cast<const i32x1 *>(ls + 512 + (wc * 64 + lane) * 4))[0];
+            const int sa_lo = (int)((((unsigned long long)(unsigned)sa2[1] << 32) | (unsigned)sa2[0]) >> sa_shift);
+            i32x8 wf[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const i32x4 lo = *reinterpret_cast<const i32x4 *>(lw + swz8(wcol + j * 16 + fr, fq));
+                const i32x4 hi = *reinterpret_cast<const i32x4 *>(lw + swz8(wcol + j * 16 + fr, 4 + fq));
+                wf[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+            static_for<0, RT / 2>([&](auto qq_c) {
+                constexpr int qq = decltype(qq_c)::value;
+                i32x8 af[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const i32x4 lo = *reinterpret_cast<const i32x4 *>(la + swz8(qq * 32 + i * 16 + fr, fq));
+                    const i32x4 hi = *reinterpret_cast<const i32x4 *>(la + swz8(qq * 32 + i * 16 + fr, 4 + fq));
+                    af[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+                static_for<0, 2>([&](auto i_c) {
+                    constexpr int i = decltype(i_c)::value, it = qq * 2 + i;
+                    static_for<0, 4>([&](auto j_c) {
+                        constexpr int j = decltype(j_c)::value;
+                        acc[it][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[j], af[i], acc[it][j], 0, 0, j, sw, it, sa_lo);
+                    });
+                });
+            });
+            --inflight;
+            sc = sc == NST - 1 ? 0 : sc + 1;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave has read the last k-step: its buffer is free
+        const int sfree = sc == 0 ? NST - 1 : sc - 1;
+        mx_tile_epilogue<EPI, BM>(a, acc, reinterpret_cast<float *>(lds + sfree * STAGE + wave * MX_EPI_PATCH), m0, n0, z0, lane, wr, wc, M, MB);
+        have = tile_of(++round, m0, n0, z0);
     }
 }
 
@@ -452,14 +597,17 @@ void launch_gemm_mx(const GemmMxArgs &args, int epi, hipStream_t st) {
              "gemm (mx): batch strides (bf16 rows only)");
     // Tile height: the one with the shortest estimated launch, rounds of <= 256 resident tiles x (k-steps x time of a k-step +
     // epilogue), with the k-step and epilogue times measured per height (us; mb_gemm_mx): M = 1500 runs fc2 on 64-row tiles
-    // (120 of them), fc1 and Q|K|V on 128-row tiles (240 / 180: one round), batched passes on 256-row tiles.  Any choice
-    // gives the same bits.
+    // (120 of them), fc1 and Q|K|V on 128-row tiles (240 / 180: one round), batched passes on 256-row tiles.  64-row tiles
+    // over a long K (fc2) run on the three-buffer kernel: measured 41.3 -> 34.8 us for one window's fc2, 42.9 -> 38.5 for
+    // two; over K = 1280, and at 128 rows (where the staging bandwidth, not the latency of a step, is the limit), the
+    // two-buffer kernel is as fast or faster.  Any choice gives the same bits.
+    constexpr int MX_S3_MIN_STEPS = 20;
     const long nt = (long)(a.N / 256) * a.nz;
     const int nk = a.K / 128;
     int bm = 256;
     double best = 1e30;
     for (int cand : {256, 128, 64}) {
-        const double t_k = cand == 256 ? 1.9 : cand == 128 ? 1.3 : 1.0, t_e = cand == 256 ? 6.0 : cand == 128 ? 4.0 : 2.5;
+        const double t_k = cand == 256 ? 1.9 : cand == 128 ? 1.3 : nk < MX_S3_MIN_STEPS ? 1.0 : 0.82, t_e = cand == 256 ? 6.0 : cand == 128 ? 4.0 : 2.5;
         const double cost = (double)ceil_div<long>(nt * ceil_div(a.M, cand), 256) * (nk * t_k + t_e);
         if (cost < best - 1e-9) best = cost, bm = cand;
     }
@@ -470,7 +618,8 @@ void launch_gemm_mx(const GemmMxArgs &args, int epi, hipStream_t st) {
     do {                                                                                                                    \
         if (bm == 256) hipLaunchKernelGGL((gemm_mxfp8_256_kernel<EPIv, 256>), pgrid, dim3(512), 0, st, a);                  \
         else if (bm == 128) hipLaunchKernelGGL((gemm_mxfp8_256_kernel<EPIv, 128>), pgrid, dim3(512), 0, st, a);             \
-        else hipLaunchKernelGGL((gemm_mxfp8_256_kernel<EPIv, 64>), pgrid, dim3(512), 0, st, a);                             \
+        else if (nk < MX_S3_MIN_STEPS) hipLaunchKernelGGL((gemm_mxfp8_256_kernel<EPIv, 64>), pgrid, dim3(512), 0, st, a);   \
+        else hipLaunchKernelGGL((gemm_mxfp8_s3_kernel<EPIv, 64>), pgrid, dim3(512), 0, st, a);                              \
     } while (0)
     if (epi == MXE_BF16) {
         MW_CHECK(!a.R && a.ldc % 8 == 0 && ((uintptr_t)a.C % 16) == 0, "gemm (mx): bf16 rows leave as 16-byte stores");
