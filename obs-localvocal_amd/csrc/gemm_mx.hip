@@ -404,7 +404,7 @@ __global__ __launch_bounds__(512) void gemm_mxfp8_256_kernel(GemmMxArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// The same product for few rows and a long K (fc2 of one or two windows, BM = 64), where a workgroup has one tile and its
+// The same product for few rows (one to a few windows: BM = 128 or 64), where a workgroup has one or two tiles and its
 // time is the latency of its own k-steps: THREE k-step buffers, each step's loads issued two steps ahead, and the wait at
 // the top of a step counted (`vmcnt(NL)`: the step after this one may still be in flight).  For the count to be the
 // kernel's own, no load of the k-loop has a register destination (hipcc waits for every load in flight where a loaded
@@ -596,18 +596,18 @@ void launch_gemm_mx(const GemmMxArgs &args, int epi, hipStream_t st) {
     MW_CHECK(a.nz >= 1 && (a.nz == 1 || (epi == MXE_BF16 && a.sW % 16 == 0 && a.sSW % 4 == 0 && a.sC % 8 == 0 && a.sBias % 4 == 0)),
              "gemm (mx): batch strides (bf16 rows only)");
     // Tile height: the one with the shortest estimated launch, rounds of <= 256 resident tiles x (k-steps x time of a k-step +
-    // epilogue), with the k-step and epilogue times measured per height (us; mb_gemm_mx): M = 1500 runs fc2 on 64-row tiles
-    // (120 of them), fc1 and Q|K|V on 128-row tiles (240 / 180: one round), batched passes on 256-row tiles.  64-row tiles
-    // over a long K (fc2) run on the three-buffer kernel: measured 41.3 -> 34.8 us for one window's fc2, 42.9 -> 38.5 for
-    // two; over K = 1280, and at 128 rows (where the staging bandwidth, not the latency of a step, is the limit), the
-    // two-buffer kernel is as fast or faster.  Any choice gives the same bits.
-    constexpr int MX_S3_MIN_STEPS = 20;
+    // epilogue), with the k-step and epilogue times measured per height (us): M = 1500 runs fc2 on 64-row tiles (120 of
+    // them), fc1 and Q|K|V on 128-row tiles (240 / 180: one round), batched passes on 256-row tiles.  The small tiles run on
+    // the three-buffer kernel: inside the encoder, with each layer's weights arriving from HBM, it is the faster one at
+    // every shape (one window: fc2 53 -> 39 us, fc1 21.0 -> 19.2, Q|K|V 18.6 -> 16.5; four windows' fc2 at 128 rows
+    // 65 -> 58.5); in a loop over one product, with the operands resident in L2, the two-buffer form was level or ahead
+    // at K = 1280.  Any choice gives the same bits.
     const long nt = (long)(a.N / 256) * a.nz;
     const int nk = a.K / 128;
     int bm = 256;
     double best = 1e30;
     for (int cand : {256, 128, 64}) {
-        const double t_k = cand == 256 ? 1.9 : cand == 128 ? 1.3 : nk < MX_S3_MIN_STEPS ? 1.0 : 0.82, t_e = cand == 256 ? 6.0 : cand == 128 ? 4.0 : 2.5;
+        const double t_k = cand == 256 ? 1.9 : cand == 128 ? 1.3 : 0.9, t_e = cand == 256 ? 6.0 : cand == 128 ? 4.0 : 2.5;
         const double cost = (double)ceil_div<long>(nt * ceil_div(a.M, cand), 256) * (nk * t_k + t_e);
         if (cost < best - 1e-9) best = cost, bm = cand;
     }
@@ -617,8 +617,7 @@ void launch_gemm_mx(const GemmMxArgs &args, int epi, hipStream_t st) {
 #define MX_LAUNCH(EPIv)                                                                                                     \
     do {                                                                                                                    \
         if (bm == 256) hipLaunchKernelGGL((gemm_mxfp8_256_kernel<EPIv, 256>), pgrid, dim3(512), 0, st, a);                  \
-        else if (bm == 128) hipLaunchKernelGGL((gemm_mxfp8_256_kernel<EPIv, 128>), pgrid, dim3(512), 0, st, a);             \
-        else if (nk < MX_S3_MIN_STEPS) hipLaunchKernelGGL((gemm_mxfp8_256_kernel<EPIv, 64>), pgrid, dim3(512), 0, st, a);   \
+        else if (bm == 128) hipLaunchKernelGGL((gemm_mxfp8_s3_kernel<EPIv, 128>), pgrid, dim3(512), 0, st, a);              \
         else hipLaunchKernelGGL((gemm_mxfp8_s3_kernel<EPIv, 64>), pgrid, dim3(512), 0, st, a);                              \
     } while (0)
     if (epi == MXE_BF16) {
