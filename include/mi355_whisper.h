@@ -22,7 +22,7 @@ enum mw_precision {
     MW_PRECISION_FP8 = 2,  /* MW_PRECISION_BF16 with the decoder's projection matrices and the logits matrix quantised to OCP
                               e4m3 at load (one power-of-two scale per output row) and streamed as bytes by the decode-step
                               kernels (bf16 activations, fp32 accumulate); the encoder keeps bf16 weights */
-    MW_PRECISION_FP8_MX = 3 /* MW_PRECISION_FP8 and, in the encoder, the Q|K|V, fc1 and fc2 products of every block and the cross K / V projections in MX-fp8 on
+    MW_PRECISION_FP8_MX = 3 /* MW_PRECISION_FP8 and, in the encoder, the Q|K|V, attention-output, fc1 and fc2 products of every block and the cross K / V projections in MX-fp8 on
                               the fp8 matrix cores: weights AND activations as e4m3 with one power-of-two scale per block of
                               32 along k (OCP microscaling; scale = the smallest power of two that brings the block under
                               448, round to nearest even).  Needs n_audio_state % 256 == 0 (base, small, medium, large) */

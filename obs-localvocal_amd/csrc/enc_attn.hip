@@ -38,13 +38,17 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2b));
 }
 
+// MXO: the output leaves as MX-fp8 (e4m3, one E8M0 scale per 32 dims of a row, in the A-operand scale order of gemm_mx.hip)
+// for the attention-output product of MW_PRECISION_FP8_MX, rows numbered through the windows of the pass.
+template <bool MXO>
 __global__ __launch_bounds__(256) void enc_flash_attn_kernel(const bf16_t *__restrict__ qk, const bf16_t *__restrict__ vt,
                                                              bf16_t *__restrict__ out, int n_ctx, int tp, int d, float scale_log2,
-                                                             int ldq_) {
+                                                             int ldq_, unsigned char *__restrict__ out8, unsigned char *__restrict__ osc,
+                                                             int MB) {
     // blockIdx.z: window of a batched encoder pass (each window has its own Q|K, V^T and output slab, back to back)
     qk += (long)blockIdx.z * n_ctx * ldq_;
     vt += (long)blockIdx.z * d * tp;
-    out += (long)blockIdx.z * n_ctx * d;
+    if constexpr (!MXO) out += (long)blockIdx.z * n_ctx * d;
     __shared__ __attribute__((aligned(16))) bf16_t kt[2][FK * FLD];
     __shared__ __attribute__((aligned(16))) bf16_t vs[2][64 * FLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
@@ -185,7 +189,34 @@ __global__ __launch_bounds__(256) void enc_flash_attn_kernel(const bf16_t *__res
         ls += __shfl_xor(ls, 32);
         const float inv = 1.0f / ls;
         const int q = q0 + 16 * i + fr;
-        if (q < n_ctx) {
+        if constexpr (MXO) {
+            // a row's 64 dims of this head: 16 t + 4 fq + r over the four lanes fq of the row; a block of 32 dims is t = 0, 1 or 2, 3
+            const long row = (long)blockIdx.z * n_ctx + q;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                float x[8];
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x[4 * t + r] = o[i][2 * b + t][r] * inv;
+                float amax = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) amax = fmaxf(amax, fabsf(x[r]));
+                amax = fmaxf(amax, __shfl_xor(amax, 16));
+                amax = fmaxf(amax, __shfl_xor(amax, 32));
+                const unsigned sb = mx_scale_byte(amax);
+                const float is = __uint_as_float((254u - sb) << 23);
+                if (q < n_ctx) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        int pk = __builtin_amdgcn_cvt_pk_fp8_f32(x[4 * t] * is, x[4 * t + 1] * is, 0, false);
+                        pk = __builtin_amdgcn_cvt_pk_fp8_f32(x[4 * t + 2] * is, x[4 * t + 3] * is, pk, true);
+                        *reinterpret_cast<int *>(out8 + row * d + h * 64 + 16 * (2 * b + t) + 4 * fq) = pk;
+                    }
+                    if (fq == 0) osc[mx_sa_off((int)row, 2 * h + b, MB)] = (unsigned char)sb;
+                }
+            }
+        } else if (q < n_ctx) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 uint2 pk;
@@ -203,14 +234,22 @@ __global__ __launch_bounds__(256) void enc_flash_attn_kernel(const bf16_t *__res
 }  // namespace
 
 void launch_enc_flash_attn(const void *qk, const void *vt, void *out, int n_ctx, int tp, int d, int H, hipStream_t st, int n_windows,
-                           int ldq) {
+                           int ldq, unsigned char *out_mx, unsigned char *out_mx_scales) {
     if (ldq == 0) ldq = 2 * d;
-    MW_CHECK(qk && vt && out && n_ctx > 0 && d == H * 64 && tp % FK == 0 && tp >= n_ctx && tp - n_ctx < FK && ldq >= 2 * d && ldq % 8 == 0,
+    MW_CHECK(qk && vt && (out || out_mx) && n_ctx > 0 && d == H * 64 && tp % FK == 0 && tp >= n_ctx && tp - n_ctx < FK && ldq >= 2 * d &&
+                 ldq % 8 == 0,
              "enc_flash_attn: shape");
     const float scale_log2 = (1.0f / sqrtf(64.0f)) * 1.4426950408889634f;
     MW_CHECK(n_windows >= 1 && n_windows <= 65535, "enc_flash_attn: window count");
-    hipLaunchKernelGGL(enc_flash_attn_kernel, dim3(ceil_div(n_ctx, FQ), H, n_windows), dim3(256), 0, st, (const bf16_t *)qk, (const bf16_t *)vt,
-                       (bf16_t *)out, n_ctx, tp, d, scale_log2, ldq);
+    const dim3 grid(ceil_div(n_ctx, FQ), H, n_windows);
+    if (out_mx) {
+        MW_CHECK(out_mx_scales && ((uintptr_t)out_mx % 4) == 0 && (long)n_windows * n_ctx < (1L << 30), "enc_flash_attn: MX output");
+        hipLaunchKernelGGL(enc_flash_attn_kernel<true>, grid, dim3(256), 0, st, (const bf16_t *)qk, (const bf16_t *)vt, (bf16_t *)nullptr, n_ctx,
+                           tp, d, scale_log2, ldq, out_mx, out_mx_scales, mx_row_blocks_a(n_windows * n_ctx));
+    } else {
+        hipLaunchKernelGGL(enc_flash_attn_kernel<false>, grid, dim3(256), 0, st, (const bf16_t *)qk, (const bf16_t *)vt, (bf16_t *)out, n_ctx, tp,
+                           d, scale_log2, ldq, (unsigned char *)nullptr, (unsigned char *)nullptr, 0);
+    }
     MW_HIP(hipGetLastError());
 }
 

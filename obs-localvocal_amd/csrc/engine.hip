@@ -78,6 +78,14 @@ static void mx_ln_post_cross(const Model &m, const float *x, void *enc_out_bf16,
     v.bias = m.ckv_b + d; v.sBias = 2L * d; v.alpha = 1.0f;
     launch_gemm_mx(v, MXE_BF16, s);
 }
+// x += att Wo^T + bo with the attention's rows as MX-fp8 in the workspace's row buffer (free between the Q|K|V product and
+// the second LayerNorm): written there by the fused attention itself, or quantised from its bf16 rows (unfused attention)
+static void mx_attn_out(const EncLayer &e, float *x, const MxWorkspace &w, int M, int d, hipStream_t s) {
+    GemmMxArgs g;
+    g.A = w.h8; g.SA = w.hs; g.lda = d; g.W = e.out_w8; g.SW = e.out_s8; g.ldw = d; g.C = x; g.ldc = d; g.bias = e.out_b;
+    g.R = x; g.ldr = d; g.M = M; g.N = d; g.K = d;
+    launch_gemm_mx(g, MXE_F32_RES, s);
+}
 static void mx_mlp(const EncLayer &e, float *x, void *ff, const MxWorkspace &w, int M, int d, hipStream_t s) {
     launch_layernorm_mx(x, d, e.ln2_w, e.ln2_b, nullptr, d, w.h8, d, w.hs, M, d, s);
     GemmMxArgs g;
@@ -440,16 +448,18 @@ void Hub::run_encode(EncLane &ln, const std::vector<EncRequest *> &batch) {
             g.nz0 = W; g.sA0 = (long)n_ctx * d; g.sC0 = (long)d * tp;
             launch_gemm(g, wt, wt, s);
         }
-        launch_enc_flash_attn(e_qk, e_vt, e_att, n_ctx, tp, d, H, s, W, m.enc_mx || qkv_fused ? 3 * d : 2 * d);
+        if (m.enc_mx) {
+            launch_enc_flash_attn(e_qk, e_vt, nullptr, n_ctx, tp, d, H, s, W, 3 * d, mxw.h8, mxw.hs);
+            mx_attn_out(e, e_x, mxw, M, d, s);
+            mx_mlp(e, e_x, e_ff, mxw, M, d, s);
+            continue;
+        }
+        launch_enc_flash_attn(e_qk, e_vt, e_att, n_ctx, tp, d, H, s, W, qkv_fused ? 3 * d : 2 * d);
         {
             GemmArgs g;  // x += att Wo^T + bo
             g.A = e_att; g.lda = d; g.W = e.out_w; g.ldw = d; g.C = e_x; g.ldc = d; g.bias = e.out_b;
             g.R = e_x; g.ldr = d; g.M = M; g.N = d; g.K = d;
             launch_gemm(g, wt, DType::F32, s);
-        }
-        if (m.enc_mx) {
-            mx_mlp(e, e_x, e_ff, mxw, M, d, s);
-            continue;
         }
         launch_layernorm(e_x, d, e.ln2_w, e.ln2_b, e_h, d, wt, M, d, s);
         {
@@ -905,8 +915,10 @@ void encode(Context &c, int seek) {
             g.M = n_ctx; g.N = d; g.K = d; g.trans_c = 1;
             gemm(g, wt, wt, st);
         }
-        if (c.flash_attn) {
-            launch_enc_flash_attn(c.d_qk, c.d_vt, c.d_att, n_ctx, tp, d, H, st, 1, m.enc_mx ? 3 * d : 2 * d);  // fused: scores never leave the chip
+        if (c.flash_attn && m.enc_mx) {
+            launch_enc_flash_attn(c.d_qk, c.d_vt, nullptr, n_ctx, tp, d, H, st, 1, 3 * d, mxw.h8, mxw.hs);
+        } else if (c.flash_attn) {
+            launch_enc_flash_attn(c.d_qk, c.d_vt, c.d_att, n_ctx, tp, d, H, st, 1, 2 * d);  // fused: scores never leave the chip
         } else {
             {
                 GemmArgs g;  // S_h = Q_h K_h^T, batched over heads
@@ -925,15 +937,17 @@ void encode(Context &c, int seek) {
                 gemm(g, wt, wt, st);
             }
         }
+        if (m.enc_mx) {
+            if (!c.flash_attn) launch_quantize_mx_rows_bf16(c.d_att, d, n_ctx, d, mxw.h8, d, mxw.hs, st);
+            mx_attn_out(e, c.d_x, mxw, n_ctx, d, st);
+            mx_mlp(e, c.d_x, c.d_ff, mxw, n_ctx, d, st);
+            continue;
+        }
         {
             GemmArgs g;  // x += att Wo^T + bo
             g.A = c.d_att; g.lda = d; g.W = e.out_w; g.ldw = d; g.C = c.d_x; g.ldc = d; g.bias = e.out_b;
             g.R = c.d_x; g.ldr = d; g.M = n_ctx; g.N = d; g.K = d;
             gemm(g, wt, DType::F32, st);
-        }
-        if (m.enc_mx) {
-            mx_mlp(e, c.d_x, c.d_ff, mxw, n_ctx, d, st);
-            continue;
         }
         launch_layernorm(c.d_x, d, e.ln2_w, e.ln2_b, c.d_h, d, wt, n_ctx, d, st);
         {

@@ -1,7 +1,7 @@
 // gemm_mx.hip — the encoder's large projections in MX-fp8 (MW_PRECISION_FP8_MX): OCP e4m3 elements with one E8M0 scale per
 // block of 32 consecutive k, multiplied by v_mfma_scale_f32_16x16x128_f8f6f4 — twice the bf16 MFMA rate on half the
 // operand bytes.  Replaces, inside whisper_full's encoder (/root/reference/src/whisper-utils/whisper-processing.cpp:218-219;
-// whisper.cpp's whisper_build_graph_encoder mul_mat nodes), the Q|K|V, fc1 and fc2 products of every block and the cross K / V projections.
+// whisper.cpp's whisper_build_graph_encoder mul_mat nodes), the Q|K|V, attention-output, fc1 and fc2 products of every block and the cross K / V projections.
 //
 // Operand maps of the instruction, found with exact data by tools/microbench/mb_mxfp8_probe (neither is documented in
 // the guides): lane l = (r = l & 15, g = l >> 4) supplies 32 operand bytes — bytes 0-15 are k = 16 g .. 16 g + 15, bytes
@@ -28,12 +28,6 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// E8M0 byte of the block scale for a block whose largest magnitude is amax (finite, >= 0)
-__device__ __forceinline__ unsigned mx_scale_byte(float amax) {
-    const unsigned u = __float_as_uint(amax);
-    const int e = (int)((u >> 23) & 255u) - ((u & 0x7fffffu) > 0x600000u ? 7 : 8);  // 448 = 1.75 x 2^8
-    return (unsigned)max(e, 0);
-}
 __device__ __forceinline__ float mx_inv_scale(unsigned byte) { return __uint_as_float((254u - byte) << 23); }  // 2^(127 - byte)
 __device__ __forceinline__ unsigned pack4_e4m3(float a, float b, float c, float d) {
     int pk = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
@@ -556,6 +550,14 @@ void launch_quantize_mx_rows(const float *x, long ldx, int M, int K, unsigned ch
     const long n = (long)M * (K / 32);
     hipLaunchKernelGGL((quantize_mx_kernel<float, true>), dim3((unsigned)ceil_div<long>(n, 256)), dim3(256), 0, st, x, ldx, q, ldq, s, M, K,
                        mx_row_blocks_a(M));
+    MW_HIP(hipGetLastError());
+}
+
+void launch_quantize_mx_rows_bf16(const void *x_bf16, long ldx, int M, int K, unsigned char *q, long ldq, unsigned char *s, hipStream_t st) {
+    MW_CHECK(M > 0 && K > 0 && K % 128 == 0 && ldq % 4 == 0 && ((uintptr_t)q % 4) == 0, "mx rows: K % 128, 4-byte aligned rows");
+    const long n = (long)M * (K / 32);
+    hipLaunchKernelGGL((quantize_mx_kernel<bf16_t, true>), dim3((unsigned)ceil_div<long>(n, 256)), dim3(256), 0, st, (const bf16_t *)x_bf16, ldx, q,
+                       ldq, s, M, K, mx_row_blocks_a(M));
     MW_HIP(hipGetLastError());
 }
 

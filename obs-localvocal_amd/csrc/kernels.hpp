@@ -90,6 +90,13 @@ __host__ __device__ inline size_t mx_sa_off(int m, int kb, int MB) {
 __host__ __device__ inline size_t mx_sw_off(int n, int kb, int NB) {
     return (((size_t)(kb >> 2) * NB + (n >> 6)) * 64 + ((kb & 3) * 16 + (n & 15))) * 4 + ((n >> 4) & 3);
 }
+// E8M0 byte of the block scale for a block whose largest magnitude is amax (finite, >= 0): the smallest power of two s
+// with amax / s <= 448 = 1.75 x 2^8, clamped at byte 0
+__host__ __device__ inline unsigned mx_scale_byte(float amax) {
+    const unsigned u = __builtin_bit_cast(unsigned, amax);
+    const int e = (int)((u >> 23) & 255u) - ((u & 0x7fffffu) > 0x600000u ? 7 : 8);
+    return (unsigned)(e > 0 ? e : 0);
+}
 inline int mx_row_blocks_a(int M) { return 2 * ((M + 255) / 256); }                       // 128-row blocks, padded to whole 256-row tiles
 inline size_t mx_scale_bytes_a(int M, int K) { return (size_t)(K / 128) * mx_row_blocks_a(M) * 512; }
 inline size_t mx_scale_bytes_w(int N, int K) { return (size_t)(K / 128) * (N / 64) * 256; }
@@ -97,6 +104,7 @@ inline size_t mx_scale_bytes_w(int N, int K) { return (size_t)(K / 128) * (N / 6
 void launch_quantize_mx_weights(const void *w_bf16, int N, int K, unsigned char *q, unsigned char *s, hipStream_t st);
 // fp32 [M][K] -> e4m3 bytes + scales in activation order (parity entry point; the encoder's producers quantise in place)
 void launch_quantize_mx_rows(const float *x, long ldx, int M, int K, unsigned char *q, long ldq, unsigned char *s, hipStream_t st);
+void launch_quantize_mx_rows_bf16(const void *x_bf16, long ldx, int M, int K, unsigned char *q, long ldq, unsigned char *s, hipStream_t st);
 // LayerNorm (ggml_norm, as launch_layernorm) whose result leaves as MX-fp8 (q, s) and, when out_bf16 is given, as bf16 too
 void launch_layernorm_mx(const float *x, long ldx, const float *w, const float *b, void *out_bf16, long ldo, unsigned char *q,
                          long ldq, unsigned char *s, int rows, int d, hipStream_t st);
@@ -130,8 +138,9 @@ void launch_layernorm(const float *x, long ldx, const float *w, const float *b, 
 // out = [n_ctx][d]; heads of 64
 // n_windows > 1: the windows of a batched encoder pass, slabs back to back (qk [w][n_ctx][2d], vt [w][d][tp], out [w][n_ctx][d])
 // ldq: row stride of qk in elements (0: 2 d)
+// out_mx: the output as MX-fp8 rows [n_windows * n_ctx][d] with their scales in A-operand order (gemm_mx.hip) instead of `out`
 void launch_enc_flash_attn(const void *qk, const void *vt, void *out, int n_ctx, int tp, int d, int H, hipStream_t st,
-                           int n_windows = 1, int ldq = 0);
+                           int n_windows = 1, int ldq = 0, unsigned char *out_mx = nullptr, unsigned char *out_mx_scales = nullptr);
 // vt[w][n][t] = src[(w n_ctx + t) lds + n] for t < n_ctx, 0 for n_ctx <= t < tp  (bf16; the V columns of a Q|K|V product ->
 // the transposed per-window layout the fused attention reads); d % 64 == 0, tp % 64 == 0
 void launch_transpose_v(const void *src, long lds_, void *vt, int n_ctx, int tp, int d, int n_windows, hipStream_t st);

@@ -426,8 +426,8 @@ void load_model(Model &m, const unsigned char *data, size_t size, DType wt, hipS
     m.dec_fp8 = fp8 != 0;
     m.enc_mx = fp8 >= 2;
     if (m.enc_mx && d % 256 != 0) throw std::runtime_error("MX-fp8 encoder: n_audio_state must be a multiple of 256");
-    if (m.enc_mx)  // Q|K (2 d^2), fc1 and fc2 (8 d^2) as bytes + one scale byte per 32
-        m.arena_size += Le * (11 * d * d + 11 * d * d / 32 + 6 * 256) + Ld * (2 * d * d + 2 * d * d / 32) + 2 * 256;
+    if (m.enc_mx)  // Q|K|V (3 d^2), attention output (d^2), fc1 and fc2 (8 d^2) as bytes + one scale byte per 32
+        m.arena_size += Le * (12 * d * d + 12 * d * d / 32 + 8 * 256) + Ld * (2 * d * d + 2 * d * d / 32) + 2 * 256;
     MW_HIP(hipMalloc((void **)&m.arena, m.arena_size));
     m.arena_owner = std::shared_ptr<void>(m.arena, free_device_block);
     L.staging_size = max_bytes;
@@ -463,6 +463,7 @@ void load_model(Model &m, const unsigned char *data, size_t size, DType wt, hipS
             e.fc2_b = L.vec(p + "mlp.2.bias", d);
             if (m.enc_mx) {
                 L.quantize_mx(e.qk_w, 3 * d, d, e.qk_w8, e.qk_s8);  // Q | K | V
+                L.quantize_mx(e.out_w, d, d, e.out_w8, e.out_s8);
                 L.quantize_mx(e.fc1_w, 4 * d, d, e.fc1_w8, e.fc1_s8);
                 L.quantize_mx(e.fc2_w, d, 4 * d, e.fc2_w8, e.fc2_s8);
             }

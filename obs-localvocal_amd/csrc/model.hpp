@@ -51,9 +51,10 @@ struct EncLayer {
     float *fc1_b;
     void *fc2_w;
     float *fc2_b;
-    // MX-fp8 mode (Model::enc_mx): Q|K|V (qk_w8: [3d][d]), fc1 and fc2 again as e4m3 bytes + E8M0 block scales in the order the MX GEMM's lanes
+    // MX-fp8 mode (Model::enc_mx): Q|K|V (qk_w8: [3d][d]), the attention output, fc1 and fc2 again as e4m3 bytes + E8M0 block scales in the order the MX GEMM's lanes
     // read them (kernels.hpp, mx_sw_off)
-    unsigned char *qk_w8 = nullptr, *qk_s8 = nullptr, *fc1_w8 = nullptr, *fc1_s8 = nullptr, *fc2_w8 = nullptr, *fc2_s8 = nullptr;
+    unsigned char *qk_w8 = nullptr, *qk_s8 = nullptr, *out_w8 = nullptr, *out_s8 = nullptr, *fc1_w8 = nullptr, *fc1_s8 = nullptr, *fc2_w8 = nullptr,
+                  *fc2_s8 = nullptr;
 };
 
 struct DecLayer {
@@ -102,7 +103,7 @@ struct Model {
     // the scale is a power of two — so prompt prefill (bf16 kernels) and the steps compute with one and the same model.
     // The encoder keeps bf16 weights (its GEMMs are not bound by weight bytes).
     bool dec_fp8 = false;
-    // MW_PRECISION_FP8_MX: additionally the encoder's Q|K|V, fc1 and fc2 products and the cross K / V projections run in MX-fp8 (gemm_mx.hip): e4m3 weights
+    // MW_PRECISION_FP8_MX: additionally the encoder's Q|K|V, attention-output, fc1 and fc2 products and the cross K / V projections run in MX-fp8 (gemm_mx.hip): e4m3 weights
     // AND activations with one power-of-two scale per block of 32 along k, on v_mfma_scale_f32_16x16x128_f8f6f4.  The
     // bf16 copies are kept (attention output and conv stem stay bf16).  Needs n_audio_state % 256 == 0.
     bool enc_mx = false;

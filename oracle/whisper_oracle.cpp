@@ -247,8 +247,8 @@ struct ow_context {
     int lang_id = 0;
     int n_decode_calls = 0, n_encode_calls = 0;
     std::string tmp_str;
-    // MX-fp8 twin of the engine's MW_PRECISION_FP8_MX encoder (ow_set_mx_encoder): the operands of the Q, K, V, fc1 and fc2
-    // products of every encoder block and of the cross K / V projections pass through mx_qdq_rows first (weights once, cached here)
+    // MX-fp8 twin of the engine's MW_PRECISION_FP8_MX encoder (ow_set_mx_encoder): the operands of the Q, K, V, attention-output,
+    // fc1 and fc2 products of every encoder block and of the cross K / V projections pass through mx_qdq_rows first (weights once, cached here)
     bool mx_encoder = false;
     std::map<std::string, std::vector<float>> mx_weights;
 };
@@ -559,7 +559,7 @@ void encode(ow_context &c, int mel_offset) {
     std::vector<float> h((size_t)n_ctx * d), q((size_t)n_ctx * d), k((size_t)n_ctx * d), v((size_t)n_ctx * d),
         att((size_t)n_ctx * d), tmp((size_t)n_ctx * d), ff((size_t)n_ctx * 4 * d);
     const float kq_scale = 1.0f / sqrtf((float)dh);
-    // MX twin: weights and the activation operand of the Q, K, V, fc1, fc2 (and cross K / V) products on the MX-fp8 grid
+    // MX twin: weights and the activation operand of the Q, K, V, attention-output, fc1, fc2 (and cross K / V) products on the MX-fp8 grid
     auto mxw = [&](const std::string &name, int K) -> const float * {
         if (!c.mx_encoder) return m.get(name).data();
         auto it = c.mx_weights.find(name);
@@ -609,8 +609,8 @@ void encode(ow_context &c, int mel_offset) {
                     for (int e = 0; e < dh; ++e) att[(size_t)i * d + hd * dh + e] = o[e];
                 }
         }
-        matmul_nt(tmp.data(), d, att.data(), d, m.get(p + "attn.out.weight").data(), d, m.get(p + "attn.out.bias").data(),
-                  n_ctx, d, d);
+        if (c.mx_encoder) mx_qdq_rows(att.data(), n_ctx, d, d);
+        matmul_nt(tmp.data(), d, att.data(), d, mxw(p + "attn.out.weight", d), d, m.get(p + "attn.out.bias").data(), n_ctx, d, d);
         for (size_t i = 0; i < x.size(); ++i) x[i] += tmp[i];
         layer_norm(h.data(), x.data(), m.get(p + "mlp_ln.weight").data(), m.get(p + "mlp_ln.bias").data(), n_ctx, d);
         if (c.mx_encoder) mx_qdq_rows(h.data(), n_ctx, d, d);

@@ -102,7 +102,7 @@ int ow_mel_n_len(ow_context *ctx);
 int ow_mel_n_len_org(ow_context *ctx);
 const float *ow_mel_data(ow_context *ctx); /* [n_mel][n_len] */
 int ow_encode(ow_context *ctx, int seek, int audio_ctx);
-/* MX-fp8 twin of the engine's MW_PRECISION_FP8_MX encoder: the operands of the Q, K, V, fc1 and fc2 products of every encoder
+/* MX-fp8 twin of the engine's MW_PRECISION_FP8_MX encoder: the operands of the Q, K, V, attention-output, fc1 and fc2 products of every encoder
    block and of the decoder layers' cross K / V projections go through ow_mx_qdq first (blocks of 32 along k: power-of-two scale bringing the block under 448, e4m3 elements,
    round to nearest even) */
 void ow_set_mx_encoder(ow_context *ctx, int on);

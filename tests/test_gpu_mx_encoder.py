@@ -1,4 +1,4 @@
-"""GPU: MW_PRECISION_FP8_MX — the encoder's Q|K|V, fc1 and fc2 products (and the cross K / V projections) in MX-fp8 on the fp8 matrix cores (gemm_mx.hip).
+"""GPU: MW_PRECISION_FP8_MX — the encoder's Q|K|V, attention-output, fc1 and fc2 products (and the cross K / V projections) in MX-fp8 on the fp8 matrix cores (gemm_mx.hip).
 
 The arithmetic the mode declares is restated in the oracle (oracle/whisper_oracle.cpp: mx_qdq_rows, ow_set_mx_encoder):
 per block of 32 along k the smallest power-of-two scale that brings the block under 448, e4m3 elements rounded to nearest

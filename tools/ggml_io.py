@@ -387,11 +387,11 @@ def e4m3_quantize_dequantize_rows(a: np.ndarray) -> np.ndarray:
 # MX-fp8 (OCP microscaling: e4m3 elements, one power-of-two scale per block of 32 along k): the format of the encoder
 # products MW_PRECISION_FP8_MX runs on the fp8 matrix cores (obs-localvocal_amd/csrc/gemm_mx.hip)
 # --------------------------------------------------------------------------------------------
-MX_ENCODER_SUFFIXES = (".attn.query.weight", ".attn.key.weight", ".attn.value.weight", ".mlp.0.weight", ".mlp.2.weight")
+MX_ENCODER_SUFFIXES = (".attn.query.weight", ".attn.key.weight", ".attn.value.weight", ".attn.out.weight", ".mlp.0.weight", ".mlp.2.weight")
 
 
 def is_mx_encoder_tensor(name: str) -> bool:
-    """The matrices MW_PRECISION_FP8_MX multiplies in MX-fp8: Q, K, V, fc1, fc2 of every encoder block and the decoder layers'
+    """The matrices MW_PRECISION_FP8_MX multiplies in MX-fp8: Q, K, V, attention output, fc1, fc2 of every encoder block and the decoder layers'
     cross K / V projections of the encoder's output."""
     return (name.startswith("encoder.blocks.") and name.endswith(MX_ENCODER_SUFFIXES)) or \
         (name.startswith("decoder.blocks.") and name.endswith((".cross_attn.key.weight", ".cross_attn.value.weight")))
