@@ -18,6 +18,7 @@
 
 #include <hip/hip_bf16.h>
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace mw {
@@ -612,6 +613,10 @@ void launch_gemm_mx(const GemmMxArgs &args, int epi, hipStream_t st) {
         const double t_k = cand == 256 ? 1.9 : cand == 128 ? 1.3 : 0.9, t_e = cand == 256 ? 6.0 : cand == 128 ? 4.0 : 2.5;
         const double cost = (double)ceil_div<long>(nt * ceil_div(a.M, cand), 256) * (nk * t_k + t_e);
         if (cost < best - 1e-9) best = cost, bm = cand;
+    }
+    if (const char *e = getenv("MI355_WHISPER_MX_TILE_ROWS")) {  // development / tests: a given tile height (same bits by construction)
+        const int v = atoi(e);
+        if (v == 256 || v == 128 || v == 64) bm = v;
     }
     const long tiles = nt * ceil_div(a.M, bm);
     MW_CHECK(tiles < (1L << 28), "gemm (mx): tile count");

@@ -88,6 +88,28 @@ def test_mx_quantisers_bit_exact_and_product_against_decoded_operands(pkg, M, K,
     print(f"M={M} K={K} N={N}: fp32 rows worst err / sum|a w| = {(err / (mag + 1e-30)).max():.2e}; GELU rows equal to the rule on {100 * same:.2f} % of the elements")
 
 
+@pytest.mark.parametrize("M,K,N", [(6200, 1280, 2560), (2100, 128, 1024), (1500, 5120, 1280)])
+def test_every_tile_height_gives_the_same_bits(pkg, monkeypatch, M, K, N):
+    """The launcher picks 256-, 128- or 64-row tiles by an estimated launch time; an output element is the same chain of
+    MFMAs whatever the tile.  Forced heights (MI355_WHISPER_MX_TILE_ROWS) on shapes with several tiles per workgroup on
+    the small-tile kernel (its loads run two k-steps ahead, across tile ends), a single k-step, and a ragged last tile."""
+    rng = np.random.default_rng(M * 7 + K + N)
+    A, W = _operands(rng, M, K, N)
+    bias = (rng.standard_normal(N) * 0.3).astype(np.float32)
+    R = rng.standard_normal((M, N)).astype(np.float32)
+    out = {}
+    for rows in ("256", "128", "64"):
+        monkeypatch.setenv("MI355_WHISPER_MX_TILE_ROWS", rows)
+        out[rows] = (pkg.mx_gemm(A, W, bias=bias, R=R, epilogue=pkg.MXE_F32_RES)[0], pkg.mx_gemm(A, W, bias=bias, epilogue=pkg.MXE_BF16)[0],
+                     pkg.mx_gemm(A, W, bias=bias, epilogue=pkg.MXE_MX_GELU)[0])
+    monkeypatch.delenv("MI355_WHISPER_MX_TILE_ROWS")
+    chosen = pkg.mx_gemm(A, W, bias=bias, R=R, epilogue=pkg.MXE_F32_RES)[0]
+    for rows in ("128", "64"):
+        for a, b in zip(out["256"], out[rows]):
+            assert np.array_equal(a, b), rows
+    assert np.array_equal(chosen, out["256"][0])
+
+
 def test_layernorm_mx_rows_follow_the_rule(pkg):
     rng = np.random.default_rng(5)
     rows, d = 203, 1280
