@@ -596,7 +596,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GS == 1 ? 4
 // With one workgroup per CU nothing hides a tile's prologue and epilogue (~20 us per round of tiles, as much as a K = 1280
 // k-loop): the workgroups are PERSISTENT — min(tiles, 256) of them, each walking tiles of an XCD-contiguous range — and the
 // first k-step of a workgroup's next tile is issued before the epilogue of the current one, so the stores of tile i and the
-// cold loads of tile i + 1 overlap.  No batch dimension; needs K % 64 == 0, N % 256 == 0; no transposed store.
+// cold loads of tile i + 1 overlap.  Batch members (GemmArgs::nz0 x nz1) are further tiles of the same walk; needs
+// K % 64 == 0, N % 256 == 0; no transposed store.
 // The epilogue's shape is a compile-time choice (HAS_R: fp32 residual added, GELU: tanh-GELU): as run-time branches around
 // its loads and stores every slice ended in a wait at the branch's join.
 template <typename TOUT, bool HAS_R, bool GELU>
@@ -608,27 +609,32 @@ __global__ __launch_bounds__(512) void gemm_bf16_256_kernel(GemmArgs a) {
     const bf16_t *A = (const bf16_t *)a.A, *W = (const bf16_t *)a.W;
     TOUT *C = (TOUT *)a.C;
     const int M = a.M, N = a.N, K = a.K;
-    const int tiles_n = N / 256, tiles_m = (M + 255) / 256, ntiles = tiles_m * tiles_n, per_xcd = (ntiles + 7) / 8;
+    const int tiles_n = N / 256, tiles_m = (M + 255) / 256, tiles_z = tiles_m * tiles_n, ntiles = tiles_z * a.nz0 * a.nz1, per_xcd = (ntiles + 7) / 8;
     auto swz8 = [](int r, int c) { return r * RB + ((c ^ (r & 7)) << 4); };
     // tile of round r: workgroups that share an XCD (ids equal mod 8) walk one contiguous range of the tile order (N-tile
-    // fastest), so what an XCD's workgroups hold at one time is a compact block of A panels x all W panels
-    auto tile_of = [&](int r, int &m0, int &n0) -> bool {
+    // fastest, batch member slowest), so what an XCD's workgroups hold at one time is a compact block of A panels x all W
+    // panels of one or two batch members
+    auto tile_of = [&](int r, int &m0, int &n0, int &z) -> bool {
         const int L = blockIdx.x + r * gridDim.x, j = L >> 3, p = (L & 7) * per_xcd + j;
         if (j >= per_xcd || p >= ntiles) return false;
-        m0 = (p / tiles_n) * 256;
-        n0 = (p % tiles_n) * 256;
+        z = p / tiles_z;
+        const int q = p - z * tiles_z;
+        m0 = (q / tiles_n) * 256;
+        n0 = (q % tiles_n) * 256;
         return true;
     };
     // piece q of this wave in a half-tile: rows 8 * wave + 64 * q .. + 7; lane -> row lane >> 3, slot lane & 7, global chunk slot ^ (row & 7)
     const bf16_t *ga[2][2], *gw[2][2];
-    auto point = [&](int m0, int n0) {
+    auto point = [&](int m0, int n0, int z) {
+        const int z0 = z / a.nz1, z1 = z - z0 * a.nz1;
+        const bf16_t *Az = A + z0 * a.sA0 + z1 * a.sA1, *Wz = W + z0 * a.sW0 + z1 * a.sW1;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int row = 8 * wave + 64 * q + (lane >> 3), chk = (lane & 7) ^ (row & 7);
-                ga[h][q] = A + (long)min(m0 + 128 * h + row, M - 1) * a.lda + chk * 8;
-                gw[h][q] = W + (long)min(n0 + 128 * h + row, N - 1) * a.ldw + chk * 8;
+                ga[h][q] = Az + (long)min(m0 + 128 * h + row, M - 1) * a.lda + chk * 8;
+                gw[h][q] = Wz + (long)min(n0 + 128 * h + row, N - 1) * a.ldw + chk * 8;
             }
     };
     const int nk = K / BK;
@@ -653,10 +659,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_256_kernel(GemmArgs a) {
                 __builtin_amdgcn_global_load_lds((gptr_t)(gw[h][q] + off), (lptr_t)(sw + h * HALF + 64 * q * RB), 16, 0, 0);
     };
     const int fr = lane & 15, fq = lane >> 4;
-    int m0 = 0, n0 = 0, round = 0;
-    bool have = tile_of(0, m0, n0);  // workgroup-uniform throughout
+    int m0 = 0, n0 = 0, zz = 0, round = 0;
+    bool have = tile_of(0, m0, n0, zz);  // workgroup-uniform throughout
     if (have) {
-        point(m0, n0);
+        point(m0, n0, zz);
         issue_a(0, 0);
         issue_w(0, 0);
     }
@@ -667,15 +673,15 @@ __global__ __launch_bounds__(512) void gemm_bf16_256_kernel(GemmArgs a) {
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
-        int m1 = 0, n1 = 0;
-        const bool have_next = tile_of(round + 1, m1, n1);
+        int m1 = 0, n1 = 0, z1n = 0;
+        const bool have_next = tile_of(round + 1, m1, n1, z1n);
         for (int kt = 0; kt < nk; ++kt) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();  // this step is in LDS for every wave; every wave is done with the other buffer
             const unsigned char *la = lds + par * STAGE + wr * HALF, *lw = lds + par * STAGE + (2 + (wc >> 1)) * HALF;
             const int wcol = (wc & 1) * 64;
             const bool last = kt + 1 == nk;
-            if (last && have_next) point(m1, n1);  // the loads below then fetch step 0 of the next tile
+            if (last && have_next) point(m1, n1, z1n);  // the loads below then fetch step 0 of the next tile
             const bool more = !last || have_next;
             const int nkt = last ? 0 : kt + 1;
             if (more) issue_a(nkt, par ^ 1);
@@ -711,6 +717,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_256_kernel(GemmArgs a) {
             constexpr int SROW = 64 + 4;  // floats per staged row (padding: conflict-free 16-byte column accesses)
             float *stg = reinterpret_cast<float *>(lds + (par ^ 1) * STAGE + wave * (16 * SROW * 4 + 256));
             const int ncol0 = n0 + wc * 64;
+            const int zb0 = zz / a.nz1, zb1 = zz - zb0 * a.nz1;  // this tile's batch member
+            TOUT *const Cz = C + zb0 * a.sC0 + zb1 * a.sC1;
+            const float *const bias_z = a.bias ? a.bias + zb0 * a.sB0 + zb1 * a.sB1 : nullptr;
+            const float *const R_z = HAS_R ? a.R + zb0 * a.sR0 + zb1 * a.sR1 : nullptr;
             // A row predicate around the stores made the compiler sink each slice's work under it and open every one of the
             // 16 predicated blocks with s_waitcnt vmcnt(0): every store waited for the acknowledgement of the one before
             // (and the first for the next tile's DMA).  Only the last row of tiles can be partial (M = windows x 1500), so the
@@ -725,7 +735,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_256_kernel(GemmArgs a) {
                 // measured 109 vs 92 us (attention output) and 290 vs 273 us (fc2) at M = 24 000: all 256 CUs read and write
                 // the same fp32 stream at once, and interleaved bursts of both cost more than they hide.
                 const int erow = lane >> 4, ecol = 4 * (lane & 15), nb = ncol0 + ecol;
-                const float4 b4 = *reinterpret_cast<const float4 *>(a.bias ? a.bias + nb : a.epi_zero);
+                const float4 b4 = *reinterpret_cast<const float4 *>(bias_z ? bias_z + nb : a.epi_zero);
 #pragma unroll
                 for (int i8 = 0; i8 < 8; ++i8) {
 #pragma unroll
@@ -739,7 +749,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_256_kernel(GemmArgs a) {
 #pragma unroll
                     for (int it = 0; it < 4; ++it) {
                         const int m = min(mrow0 + erow + 4 * it, M - 1);
-                        if constexpr (HAS_R) rv[it] = *reinterpret_cast<const float4 *>(a.R + (long)m * a.ldr + nb);
+                        if constexpr (HAS_R) rv[it] = *reinterpret_cast<const float4 *>(R_z + (long)m * a.ldr + nb);
                         else rv[it] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                     }
 #pragma unroll
@@ -752,7 +762,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_256_kernel(GemmArgs a) {
                             for (int r = 0; r < 4; ++r) x[r] = gelu_fast(x[r]);
                         }
                         x[0] += rv[it].x; x[1] += rv[it].y; x[2] += rv[it].z; x[3] += rv[it].w;
-                        if (mr < M) *reinterpret_cast<float4 *>(C + (long)mr * a.ldc + nb) = make_float4(x[0], x[1], x[2], x[3]);
+                        if (mr < M) *reinterpret_cast<float4 *>(Cz + (long)mr * a.ldc + nb) = make_float4(x[0], x[1], x[2], x[3]);
                     }
                 }
             } else {
@@ -760,8 +770,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_256_kernel(GemmArgs a) {
                 // per instruction — half the store instructions of the 8-byte form, and the stores, not the bytes, bound this tail
                 static_assert(!HAS_R, "bf16 outputs carry no residual");
                 const int erow = lane >> 3, ecol = 8 * (lane & 7), nb = ncol0 + ecol;
-                const float *bp = a.bias ? a.bias + nb : a.epi_zero;
-                const float4 b0 = *reinterpret_cast<const float4 *>(bp), b1 = *reinterpret_cast<const float4 *>(a.bias ? bp + 4 : bp);
+                const float *bp = bias_z ? bias_z + nb : a.epi_zero;
+                const float4 b0 = *reinterpret_cast<const float4 *>(bp), b1 = *reinterpret_cast<const float4 *>(bias_z ? bp + 4 : bp);
                 const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
                 for (int i8 = 0; i8 < 8; ++i8) {
@@ -792,7 +802,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_256_kernel(GemmArgs a) {
                         using u32x4n = __attribute__((ext_vector_type(4))) unsigned;
                         const u32x4n out4 = {pk[0], pk[1], pk[2], pk[3]};
                         if (FULL || mr < M)  // 60-120 MB read once by the next kernel: streaming stores
-                            __builtin_nontemporal_store(out4, reinterpret_cast<u32x4n *>(C + (long)mr * a.ldc + nb));
+                            __builtin_nontemporal_store(out4, reinterpret_cast<u32x4n *>(Cz + (long)mr * a.ldc + nb));
                     }
                 }
             }
@@ -802,6 +812,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_256_kernel(GemmArgs a) {
         }
         m0 = m1;
         n0 = n1;
+        zz = z1n;
         have = have_next;
         ++round;
     }
@@ -852,8 +863,9 @@ void launch_gemm(const GemmArgs &args, DType in, DType out, hipStream_t st) {
     const bool many = in == DType::BF16 && a.K % 64 == 0 && a.K >= 256 && tiles128 >= 900;  // (also the transposed V projection)
     // 256 x 256 persistent tiles once they fill the chip (>= 200 of them for 256 CUs): fc2 / attention output at M = 12000,
     // Q|K and fc1 from M = 6000 on
-    const long tiles256 = (long)(a.N / 256) * ceil_div(a.M, 256);
-    const bool big = in == DType::BF16 && !a.trans_c && a.K % 64 == 0 && a.K >= 256 && a.N % 256 == 0 && a.nz0 * a.nz1 == 1 &&
+    // (batch members are tiles like any other: the cross K / V of all decoder layers for one window, 960 tiles)
+    const long tiles256 = (long)(a.N / 256) * ceil_div(a.M, 256) * a.nz0 * a.nz1;
+    const bool big = in == DType::BF16 && !a.trans_c && a.K % 64 == 0 && a.K >= 256 && a.N % 256 == 0 && tiles256 < (1L << 28) &&
                      a.epi_vec && (a.glds == 8 || (a.glds == 0 && tiles256 >= 200)) &&
                      // the epilogue shapes the 256 x 256 kernel is instantiated for; its bf16 rows leave as 16-byte stores
                      ((out == DType::F32 && a.act == ACT_NONE) || (out == DType::BF16 && !a.R && a.ldc % 8 == 0 && ((uintptr_t)a.C % 16) == 0));
@@ -896,7 +908,7 @@ void launch_gemm(const GemmArgs &args, DType in, DType out, hipStream_t st) {
     } while (0)
     if (big) {
         // persistent: one workgroup per CU at most, a multiple of 8 so that every XCD's range is walked in step
-        const dim3 pgrid((unsigned)std::min<long>(ceil_div<long>((long)grid.x * grid.y, 8) * 8, 256));
+        const dim3 pgrid((unsigned)std::min<long>(ceil_div<long>(tiles256, 8) * 8, 256));
         const bool gelu = a.act == ACT_GELU;
         if (out == DType::F32 && a.R) hipLaunchKernelGGL((gemm_bf16_256_kernel<float, true, false>), pgrid, dim3(512), 0, st, a);
         else if (out == DType::F32) hipLaunchKernelGGL((gemm_bf16_256_kernel<float, false, false>), pgrid, dim3(512), 0, st, a);
