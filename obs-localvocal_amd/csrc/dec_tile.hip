@@ -918,6 +918,31 @@ __global__ __launch_bounds__(MT) void cross_attn_lean_kernel(const float *q, con
     cross_attn_lean<NB, OT, DESC>(q, kc, vc, groups, k_off, v_off, part, out, head_cnt, n, H, d, n_ctx, splits, lds);
 }
 
+// Measurement only (MI355_WHISPER_CROSS_PREFETCH): reads exactly the K / V bytes that workgroup blockIdx.x of
+// cross_attn_lean_kernel<.., DESC = true> will read, with the same grid, and drops them — run on a parallel branch of the
+// step's graph, ahead of the cross-attention of the same layer.
+__global__ __launch_bounds__(MT) void cross_touch_kernel(const StepGroup *groups, long k_off, long v_off, int H, int d, int splits, int *sink) {
+    const int tid = threadIdx.x;
+    const int hs = H * splits, g = blockIdx.x / hs, rem = blockIdx.x - g * hs;
+    const int h = rem / splits, sp = rem - h * splits;
+    const StepGroup *G = groups + g;
+    const int n_ctx = G->n_ctx;
+    const bf16_t *kc = G->cross + k_off, *vc = G->cross + v_off;
+    const int per = (n_ctx + splits - 1) / splits;
+    const int j0 = sp * per, nk = min(per, n_ctx - j0);
+    const int last = max(nk - 1, 0) + min(j0, n_ctx - 1);
+    const int kk = tid >> 3, e8 = tid & 7;
+    unsigned acc = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int key = kk + 64 * i;
+        const long off = (long)(key < nk ? j0 + key : last) * d + h * 64 + e8 * 8;
+        const u32x4v a = *reinterpret_cast<const u32x4v *>(kc + off), b = *reinterpret_cast<const u32x4v *>(vc + off);
+        acc ^= a[0] ^ a[1] ^ a[2] ^ a[3] ^ b[0] ^ b[1] ^ b[2] ^ b[3];
+    }
+    if (acc == 0x9e3779b9u && sink) sink[0] = 1;  // (keeps the loads; practically never taken)
+}
+
 // ---- head of a batched step: the StepBlock straight from pinned host memory ----
 // Blocks [0, n_groups * KV_SLOTS): the requests' deferred beam reshuffles of their index tables; the next n_rows blocks
 // embed one token each; the last block copies the StepBlock into device memory for the kernels behind.
@@ -1101,6 +1126,12 @@ void launch_cross_attn_batch(const float *q, const StepBlock *blk, long k_off, l
     else
         hipLaunchKernelGGL((cross_attn_lean_kernel<16, bf16_t, true>), grid, block, 0, st, q, (const bf16_t *)nullptr, (const bf16_t *)nullptr,
                            blk->groups, k_off, v_off, partial, (bf16_t *)out, head_cnt, 0, H, d, 0, splits);
+    MW_HIP(hipGetLastError());
+}
+
+void launch_cross_touch_batch(const StepBlock *blk, long k_off, long v_off, int n_groups, int H, int d, int splits, int *sink, hipStream_t st) {
+    MW_CHECK(blk && n_groups >= 1 && n_groups <= STEP_MAX_GROUPS && d == H * 64 && splits >= 1 && splits <= CROSS_SPLITS_MAX, "cross_touch: shape");
+    hipLaunchKernelGGL(cross_touch_kernel, dim3(n_groups * H * splits), dim3(MT), 0, st, blk->groups, k_off, v_off, H, d, splits, sink);
     MW_HIP(hipGetLastError());
 }
 

@@ -247,6 +247,8 @@ Hub::~Hub() {
         if (ln.h_res) (void)hipHostFree(ln.h_res);
         for (auto &kv : ln.graphs) (void)hipGraphExecDestroy(kv.second);
         if (ln.st) (void)hipStreamDestroy(ln.st);
+        if (ln.st2) (void)hipStreamDestroy(ln.st2);
+        for (hipEvent_t e : ln.ev_branch) (void)hipEventDestroy(e);
     }
     for (EncLane &el : enc_lanes) {
         void *ptrs[] = {el.e_conv_in, el.e_x1, el.e_h, el.e_qk, el.e_vt, el.e_att, el.e_ff, el.e_x, el.e_mx};
@@ -264,6 +266,7 @@ std::shared_ptr<Hub> create_hub(const Model &m, int device, bool use_graphs) {
     h->m.mel_tab_owner.reset();
     h->m.hub.reset();
     h->use_graphs = use_graphs;
+    h->cross_prefetch = getenv("MI355_WHISPER_CROSS_PREFETCH") != nullptr;  // measurement only
     const HParams &hp = m.hp;
     const size_t d = hp.n_text_state, H = hp.n_text_head, nv = hp.n_vocab, R = STEP_MAX_ROWS;
     // Plain streams on purpose.  High-priority lane streams (hipStreamCreateWithPriority) changed nothing with one or two
@@ -274,6 +277,11 @@ std::shared_ptr<Hub> create_hub(const Model &m, int device, bool use_graphs) {
     for (int li = 0; li < h->n_lanes; ++li) {
         Hub::Lane &ln = h->lanes[li];
         MW_HIP(hipStreamCreateWithFlags(&ln.st, hipStreamNonBlocking));
+        if (h->cross_prefetch) {
+            MW_HIP(hipStreamCreateWithFlags(&ln.st2, hipStreamNonBlocking));
+            ln.ev_branch.resize(2 * (size_t)m.hp.n_text_layer);
+            for (hipEvent_t &e : ln.ev_branch) MW_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
         MW_HIP(hipHostMalloc((void **)&ln.h_blk, sizeof(StepBlock)));
         memset(ln.h_blk, 0, sizeof(StepBlock));
         MW_HIP(hipHostGetDevicePointer((void **)&ln.h_blk_dev, ln.h_blk, 0));
@@ -687,6 +695,13 @@ void Hub::run(Lane &ln, const std::vector<StepRequest *> &batch) {
         for (int l = 0; l < hp.n_text_layer; ++l) {
             const DecLayer &e = m.dec[l];
             const long kv_off = (long)(l * kv_layer);
+            if (cross_prefetch) {  // measurement: this layer's cross K / V touched on a parallel branch while the chain runs up to cross-q
+                const long ko = (long)l * 2 * T * d;
+                MW_HIP(hipEventRecord(ln.ev_branch[2 * l], st));
+                MW_HIP(hipStreamWaitEvent(ln.st2, ln.ev_branch[2 * l], 0));
+                launch_cross_touch_batch(d_blk, ko, ko + (long)T * d, G, H, d, splits, (int *)nullptr, ln.st2);
+                MW_HIP(hipEventRecord(ln.ev_branch[2 * l + 1], ln.st2));
+            }
             {
                 GemvArgs g;  // LN + Q|K|V; K and V go straight into each row's cache
                 g.x = d_x; g.ldx = d; g.n = R; g.W = e.qkv_w; if (m.dec_fp8) { g.W8 = e.qkv_w8; g.w_scale = e.qkv_s; } g.bias = e.qkv_b; g.N = 3 * d; g.K = d;
@@ -709,6 +724,7 @@ void Hub::run(Lane &ln, const std::vector<StepRequest *> &batch) {
                 proj(g, 0);
             }
             const long k_off = (long)l * 2 * T * d, v_off = k_off + (long)T * d;
+            if (cross_prefetch) MW_HIP(hipStreamWaitEvent(st, ln.ev_branch[2 * l + 1], 0));
             bracket(GEMV_N_TAGS + 1, [&]() {
                 launch_cross_attn_batch(d_q, d_blk, k_off, v_off, d_part, d_attd, d_head_cnt, R, g_rows_max, G, H, d, n_ctx_max, splits, st);
             });

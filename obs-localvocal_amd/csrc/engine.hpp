@@ -104,7 +104,11 @@ struct Hub {
         std::unordered_map<uint64_t, hipGraphExec_t> graphs;
         std::vector<uint64_t> graph_lru;
         bool busy = false;
+        // measurement only (MI355_WHISPER_CROSS_PREFETCH): a second stream and fork / join events for a parallel graph branch
+        hipStream_t st2 = nullptr;
+        std::vector<hipEvent_t> ev_branch;
     };
+    bool cross_prefetch = false;
     int device = 0;
     Model m;  // non-owning view of the weights (owners reset: the hub is owned BY the models that point to it)
     Lane lanes[N_LANES];

@@ -279,6 +279,7 @@ void launch_self_attn_batch(const float *q, const StepBlock *blk, const int *row
                             int n_text_ctx, hipStream_t st);
 // cross-attention of every request's rows over its own context's K / V (element offsets of the layer's K and V inside
 // a context's cross buffer); head_cnt: n_groups * H zeroed counters, left zeroed
+void launch_cross_touch_batch(const StepBlock *blk, long k_off, long v_off, int n_groups, int H, int d, int splits, int *sink, hipStream_t st);
 void launch_cross_attn_batch(const float *q, const StepBlock *blk, long k_off, long v_off, float *partial, void *out,
                              unsigned *head_cnt, int n_rows, int max_group_rows, int n_groups, int H, int d, int n_ctx_max, int splits,
                              hipStream_t st);

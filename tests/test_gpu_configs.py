@@ -121,9 +121,11 @@ def test_every_environment_switch_gives_the_same_results(pkg, model_file, monkey
     assert len(base_tok) >= 20
     #  * MI355_WHISPER_NO_BATCH: the context runs its own steps and encoder pass instead of the hub's -> identical tokens;
     #  * MI355_WHISPER_LANES=1: one step lane -> identical tokens;
-    #  * MI355_WHISPER_PRECISION=fp8 is a precision, not a kernel switch: covered by test_gpu_full_dims.py.
+    #  * MI355_WHISPER_PRECISION=fp8 is a precision, not a kernel switch: covered by test_gpu_full_dims.py;
+    #  * MI355_WHISPER_CROSS_PREFETCH (measurement only): a parallel branch in the step graph that reads each
+    #    layer's cross K / V ahead of its cross-attention -> identical tokens.
     for switch in ("MI355_WHISPER_NO_FUSED_SAMPLE", "MI355_WHISPER_NO_STEP_BEGIN", "MI355_WHISPER_NO_GRAPH", "MI355_WHISPER_NO_BATCH",
-                   "MI355_WHISPER_LANES"):
+                   "MI355_WHISPER_LANES", "MI355_WHISPER_CROSS_PREFETCH"):
         monkeypatch.setenv(switch, "1")
         tok, seg = _forced_tokens(pkg, path, pcm, 24, pkg.PRECISION_BF16, strategy=1, language="en")
         monkeypatch.delenv(switch)
