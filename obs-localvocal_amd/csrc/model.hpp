@@ -105,7 +105,7 @@ struct Model {
     bool dec_fp8 = false;
     // MW_PRECISION_FP8_MX: additionally the encoder's Q|K|V, attention-output, fc1 and fc2 products and the cross K / V projections run in MX-fp8 (gemm_mx.hip): e4m3 weights
     // AND activations with one power-of-two scale per block of 32 along k, on v_mfma_scale_f32_16x16x128_f8f6f4.  The
-    // bf16 copies are kept (attention output and conv stem stay bf16).  Needs n_audio_state % 256 == 0.
+    // bf16 copies stay resident (what the MX weights were quantised from; the conv stem stays bf16).  Needs n_audio_state % 256 == 0.
     bool enc_mx = false;
     unsigned char *ckv_w8 = nullptr, *ckv_s8 = nullptr;  // enc_mx: the cross K | V weights [L][2][d][d] as e4m3 + block scales per matrix
     unsigned char *tok_emb8 = nullptr;
