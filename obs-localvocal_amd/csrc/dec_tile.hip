@@ -90,6 +90,11 @@ __device__ __forceinline__ void fp8x16_to_bf16(const uint4 &u, uint4 &lo, uint4 
 using bf16x8b = __attribute__((ext_vector_type(8))) __bf16;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using u32x4v = __attribute__((ext_vector_type(4))) unsigned;
+// 16 bytes through a pointer that came out of a step descriptor in memory: hipcc cannot know such a pointer's address space
+// and emits flat_load (aperture check, counted on lgkmcnt as well as vmcnt — entangled with the LDS traffic behind it);
+// the caches it points to are device memory, so the load is stated as a global one
+// (A/B on one box, headline workload: 158.5 / 158.6 -> 159.1 / 159.3 audio-s/s, profiles/r03_ab_runs.txt)
+__device__ __forceinline__ u32x4v ldg16(const void *p) { return *(const __attribute__((address_space(1))) u32x4v *)p; }
 
 
 enum { EPI_QKV = 0, EPI_RES = 1, EPI_SCALE = 2, EPI_GELU_BF16 = 3, EPI_GELU_F32 = 4 };
@@ -600,8 +605,9 @@ __device__ __forceinline__ void self_attn_lean(const float *q, const bf16_t *kc,
 #pragma unroll
     for (int i = 0; i < PVI; ++i) {
         const long off = ((long)iv[i] * TC + min(jj + 64 * i, np - 1)) * d + h * 64 + e8 * 8;
-        kq[i] = *reinterpret_cast<const uint4 *>(kc + off);
-        vq[i] = *reinterpret_cast<const uint4 *>(vc + off);
+        const u32x4v k4 = ldg16(kc + off), v4 = ldg16(vc + off);
+        kq[i] = make_uint4(k4[0], k4[1], k4[2], k4[3]);
+        vq[i] = make_uint4(v4[0], v4[1], v4[2], v4[3]);
     }
     __builtin_amdgcn_sched_barrier(0);  // the V loads stay in this batch (the scheduler would sink them next to their use)
     float sc[PVI], mx = -INFINITY;
@@ -788,8 +794,8 @@ __device__ __forceinline__ void cross_attn_lean(const float *q, const bf16_t *kc
     for (int i = 0; i < 2; ++i) {
         const int key = kk + 64 * i;
         const long off = (long)(key < nk ? j0 + key : last) * d + h * 64 + e8 * 8;
-        kq[i] = *reinterpret_cast<const u32x4v *>(kc + off);
-        vq[i] = *reinterpret_cast<const u32x4v *>(vc + off);
+        kq[i] = ldg16(kc + off);
+        vq[i] = ldg16(vc + off);
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- stage q, K and V^T ----
