@@ -95,6 +95,7 @@ using u32x4v = __attribute__((ext_vector_type(4))) unsigned;
 // the caches it points to are device memory, so the load is stated as a global one
 // (A/B on one box, headline workload: 158.5 / 158.6 -> 159.1 / 159.3 audio-s/s, profiles/r03_ab_runs.txt)
 __device__ __forceinline__ u32x4v ldg16(const void *p) { return *(const __attribute__((address_space(1))) u32x4v *)p; }
+__device__ __forceinline__ int ldg_i32(const int *p) { return *(const __attribute__((address_space(1))) int *)p; }
 
 
 enum { EPI_QKV = 0, EPI_RES = 1, EPI_SCALE = 2, EPI_GELU_BF16 = 3, EPI_GELU_F32 = 4 };
@@ -964,7 +965,7 @@ __global__ __launch_bounds__(256) void step_begin_batch_kernel(const StepBlock *
         if (G->reorder_flag == 0 || s < 0) return;
         const int *old_idx = G->idx_old;
         int *new_idx = G->idx_new;
-        for (int p = threadIdx.x; p <= n_past; p += 256) new_idx[j * n_text_ctx + p] = p < n_past ? old_idx[s * n_text_ctx + p] : j;
+        for (int p = threadIdx.x; p <= n_past; p += 256) new_idx[j * n_text_ctx + p] = p < n_past ? ldg_i32(old_idx + s * n_text_ctx + p) : j;
     } else if (b < n_groups * KV_SLOTS + n_rows) {
         const int i = b - n_groups * KV_SLOTS;
         const long t = hblk->rows[i].token, p = hblk->rows[i].pos;
@@ -979,7 +980,7 @@ __global__ __launch_bounds__(256) void step_begin_batch_kernel(const StepBlock *
         const int *cur = Rw->kv_idx + (long)sl * n_text_ctx, *old = G->idx_old + (long)(src < 0 ? 0 : src) * n_text_ctx;
         for (int k = threadIdx.x; k < TILE_TC_MAX; k += 256) {
             const int pp = min(k, np - 1);
-            phys[(long)i * TILE_TC_MAX + k] = re && pp <= rnp ? (pp < rnp ? old[pp] : sl) : cur[pp];
+            phys[(long)i * TILE_TC_MAX + k] = re && pp <= rnp ? (pp < rnp ? ldg_i32(old + pp) : sl) : ldg_i32(cur + pp);
         }
     } else {
         const int *src = reinterpret_cast<const int *>(hblk);
