@@ -752,6 +752,14 @@ __device__ __forceinline__ void cross_count_and_combine(const float *part, OT *o
 // row0 .. row0 + nrows - 1 attend to ITS context's K / V.
 constexpr int XK = 128;      // keys per split
 constexpr int XLDP = XK + 8; // LDS row stride (elements) of the [*][key] tiles: conflict-free 16-byte reads
+// Row stride of the transposed V tile: 65 dwords.  The tile is written by 2-byte scatter stores — a lane holds 8 dims of one
+// key, the 8 lanes of a key are 8 dims apart — and with 68 dwords per row (XLDP) the 64 lanes of a store instruction fell
+// into 8 banks; an odd dword stride spreads them over 32.  Rows are then only 4-byte aligned: the B fragments are read as
+// four dwords instead of one 16-byte piece.  Interleaved A/B on one box (profiles/r03_ab_runs.txt, `vt_*`): 9.38 / 9.58 ->
+// 8.85 / 8.79 us per launch inside graph replay, headline 159.9 -> 160.4 audio-s/s.  Dword stores after a lane swap (keys
+// 2m and 2m + 1 are 8 lanes apart: half the store instructions, none sub-dword) measured 9.09 / 8.98: not kept.
+constexpr int XVLD = XK + 2;
+static_assert(XVLD % 2 == 0 && XVLD >= XK && XVLD <= XLDP, "transposed V rows: dword-aligned, inside their region");
 constexpr int XKD = 64 + 8;  // LDS row stride of the [key][dim] K tile
 
 template <int NB, typename OT, bool DESC>
@@ -760,7 +768,7 @@ __device__ __forceinline__ void cross_attn_lean(const float *q, const bf16_t *kc
                                                 int splits, float *lds) {
     bf16_t *qb = reinterpret_cast<bf16_t *>(lds);  // [16][72]    q rows
     bf16_t *kt = qb + 16 * 72;                     // [XK][XKD]   K rows
-    bf16_t *vt = kt + XK * XKD;                    // [64][XLDP]  V transposed: [dim][key]
+    bf16_t *vt = kt + XK * XKD;                    // [64][XVLD]  V transposed: [dim][key] (the region keeps 64 rows of XLDP)
     bf16_t *pb = vt + 64 * XLDP;                   // [16][XLDP]  probabilities
     float *sc = reinterpret_cast<float *>(pb + 16 * XLDP);  // [NB][XK] scores
     float *red = sc + NB * XK;                     // [8][64][4]
@@ -811,8 +819,8 @@ __device__ __forceinline__ void cross_attn_lean(const float *q, const bf16_t *kc
         *reinterpret_cast<u32x4v *>(kt + key * XKD + e8 * 8) = kq[i];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            vt[(e8 * 8 + 2 * c) * XLDP + key] = (bf16_t)(vq[i][c] & 0xffffu);
-            vt[(e8 * 8 + 2 * c + 1) * XLDP + key] = (bf16_t)(vq[i][c] >> 16);
+            vt[(e8 * 8 + 2 * c) * XVLD + key] = (bf16_t)(vq[i][c] & 0xffffu);
+            vt[(e8 * 8 + 2 * c + 1) * XVLD + key] = (bf16_t)(vq[i][c] >> 16);
         }
     }
     lds_sync();
@@ -859,7 +867,8 @@ __device__ __forceinline__ void cross_attn_lean(const float *q, const bf16_t *kc
         for (int s2 = 0; s2 < 2; ++s2) {
             const int ks = 2 * kh + s2;
             const uint4 af = *reinterpret_cast<const uint4 *>(pb + fr * XLDP + 32 * ks + 8 * fq);
-            const uint4 bfr = *reinterpret_cast<const uint4 *>(vt + (16 * nt + fr) * XLDP + 32 * ks + 8 * fq);
+            const unsigned *bp = reinterpret_cast<const unsigned *>(vt + (16 * nt + fr) * XVLD + 32 * ks + 8 * fq);
+            const uint4 bfr = XVLD % 8 == 0 ? *reinterpret_cast<const uint4 *>(bp) : make_uint4(bp[0], bp[1], bp[2], bp[3]);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8b, af), __builtin_bit_cast(bf16x8b, bfr), acc, 0, 0, 0);
         }
         *reinterpret_cast<f32x4 *>(red + (wave * 64 + lane) * 4) = acc;
