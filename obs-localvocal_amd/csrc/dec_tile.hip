@@ -28,15 +28,39 @@ __device__ __forceinline__ float row16_sum(float v) {
     v = dpp_add<0x140>(v);  // row_mirror
     return v;
 }
+// Wave-wide sum / maximum in every lane, on DPP moves only (as ds_bpermute shuffles — what __shfl_xor compiles to — each of
+// the six steps was an LDS round trip behind its own s_waitcnt, in the middle of the attention kernels' critical paths).
+// Rows of 16 first, then row_bcast15 / row_bcast31 carry the row totals up to lane 63, whose value is broadcast as a scalar.
+// The sum adds the same pairs in the same order as the shuffle form did ((r0 + r1) + (r2 + r3)): same bits.
 __device__ __forceinline__ float wave_sum_all(float v) {
     v = row16_sum(v);
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    return v;
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, false));  // row_bcast15
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xc, 0xf, false));  // row_bcast31
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+template <int CTRL, int ROWS> __device__ __forceinline__ float dpp_max(float v) {  // (lanes outside ROWS keep their value)
+    return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROWS, 0xf, false)));
 }
 __device__ __forceinline__ float wave_max_all(float v) {
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
+    v = dpp_max<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+    v = dpp_max<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+    v = dpp_max<0x141, 0xf>(v);  // row_half_mirror
+    v = dpp_max<0x140, 0xf>(v);  // row_mirror
+    v = dpp_max<0x142, 0xa>(v);  // row_bcast15
+    v = dpp_max<0x143, 0xc>(v);  // row_bcast31
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+// v + v[lane ^ 8] (DPP row rotate by 8), v + v[lane ^ 16], v + v[lane ^ 32] (gfx950's row / half-wave swaps: both copies of v
+// go in, one comes back with the partner's value in every lane): the partners and the order of each addition are those
+// of the __shfl_xor form, without its LDS round trips
+__device__ __forceinline__ float xor8_add(float v) { return dpp_add<0x128>(v); }
+__device__ __forceinline__ float xor16_add(float v) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor32_add(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 __device__ __forceinline__ float gelu_f(float x) {
     const float c = 0.79788456080286535587989211986876f, a = 0.044715f;
@@ -619,9 +643,9 @@ __device__ __forceinline__ void self_attn_lean(const float *q, const bf16_t *kc,
         float dot = qa.x * f[0];
         dot = fmaf(qa.y, f[1], dot); dot = fmaf(qa.z, f[2], dot); dot = fmaf(qa.w, f[3], dot);
         dot = fmaf(qb.x, f[4], dot); dot = fmaf(qb.y, f[5], dot); dot = fmaf(qb.z, f[6], dot); dot = fmaf(qb.w, f[7], dot);
-        dot += __shfl_xor(dot, 1);
-        dot += __shfl_xor(dot, 2);
-        dot += __shfl_xor(dot, 4);
+        dot = dpp_add<0xB1>(dot);   // the 8 lanes of a key: lane ^ 1, lane ^ 2 (quad permutes), then the other quad of the
+        dot = dpp_add<0x4E>(dot);   // eight (row_half_mirror: every lane of a quad holds the quad's sum by then)
+        dot = dpp_add<0x141>(dot);
         sc[i] = jj + 64 * i < np ? dot : -INFINITY;
         mx = fmaxf(mx, sc[i]);
     }
@@ -644,11 +668,7 @@ __device__ __forceinline__ void self_attn_lean(const float *q, const bf16_t *kc,
     const float ws = wave_sum_all(e8 == 0 ? psum : 0.0f);  // the 8 lanes of a key hold the same weight: count it once
 #pragma unroll
     for (int q8 = 0; q8 < 8; ++q8) {
-        float v = o[q8];
-        v += __shfl_xor(v, 8);
-        v += __shfl_xor(v, 16);
-        v += __shfl_xor(v, 32);
-        o[q8] = v;
+        o[q8] = xor32_add(xor16_add(xor8_add(o[q8])));
     }
     if (lane == 0) sm[8 + wave] = ws;
     if ((lane >> 3) == 0) {
