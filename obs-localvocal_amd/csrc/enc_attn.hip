@@ -136,8 +136,7 @@ __global__ __launch_bounds__(256) void enc_flash_attn_kernel(const bf16_t *__res
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sa[i][t][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            mx = xor_max<32>(xor_max<16>(mx));  // (common.hpp: row / half-wave swaps, no LDS round trip)
             const bool moved = __builtin_amdgcn_ballot_w64(mx > m[i]) != 0;  // wave-uniform
             const float nms = -mx * scale_log2;
             float ps = 0.0f;
@@ -187,8 +186,7 @@ __global__ __launch_bounds__(256) void enc_flash_attn_kernel(const bf16_t *__res
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         float ls = l[i];
-        ls += __shfl_xor(ls, 16);
-        ls += __shfl_xor(ls, 32);
+        ls = xor_sum<32>(xor_sum<16>(ls));
         const float inv = 1.0f / ls;
         const int q = q0 + 16 * i + fr;
         if constexpr (MXO) {
@@ -204,8 +202,7 @@ __global__ __launch_bounds__(256) void enc_flash_attn_kernel(const bf16_t *__res
                 float amax = 0.0f;
 #pragma unroll
                 for (int r = 0; r < 8; ++r) amax = fmaxf(amax, fabsf(x[r]));
-                amax = fmaxf(amax, __shfl_xor(amax, 16));
-                amax = fmaxf(amax, __shfl_xor(amax, 32));
+                amax = xor_max<32>(xor_max<16>(amax));
                 const unsigned sb = mx_scale_byte(amax);
                 const float is = __uint_as_float((254u - sb) << 23);
                 if (q < n_ctx) {

@@ -10,14 +10,8 @@ namespace mw {
 
 namespace {
 
-__device__ __forceinline__ float wave_sum(float v) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
-}
+__device__ __forceinline__ float wave_sum(float v) { return wave_sum_desc(v); }  // (common.hpp: no LDS shuffles, same order)
+__device__ __forceinline__ float wave_max(float v) { return wave_max_desc(v); }
 __device__ __forceinline__ void store_out(float *p, float v) { *p = v; }
 __device__ __forceinline__ void store_out(bf16_t *p, float v) {
     __hip_bfloat16 h = __float2bfloat16(v);

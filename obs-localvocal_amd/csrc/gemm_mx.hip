@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void layernorm_mx_kernel(const float *__restri
         v[i] = *reinterpret_cast<const float4 *>(xr + (i * 64 + lane) * 4);
         sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    sum = wave_sum_desc(sum);  // (common.hpp: the shuffle form's partners and order, without its LDS round trips)
     const float mean = sum / (float)d;
     float s2 = 0.0f;
 #pragma unroll
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void layernorm_mx_kernel(const float *__restri
         v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
         s2 += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
     }
-    for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o);
+    s2 = wave_sum_desc(s2);
     const float rstd = 1.0f / sqrtf(s2 / (float)d + 1e-5f);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -120,9 +120,7 @@ __global__ __launch_bounds__(256) void layernorm_mx_kernel(const float *__restri
             *reinterpret_cast<uint2 *>(out + (long)row * ldo + c) = pk;
         }
         float amax = fmaxf(fmaxf(fabsf(y0), fabsf(y1)), fmaxf(fabsf(y2), fabsf(y3)));
-        amax = fmaxf(amax, __shfl_xor(amax, 1));
-        amax = fmaxf(amax, __shfl_xor(amax, 2));
-        amax = fmaxf(amax, __shfl_xor(amax, 4));
+        amax = xor_max<4>(xor_max<2>(xor_max<1>(amax)));
         const unsigned sb = mx_scale_byte(amax);
         const float inv = mx_inv_scale(sb);
         *reinterpret_cast<unsigned *>(q + (long)row * ldq + c) = pack4_e4m3(y0 * inv, y1 * inv, y2 * inv, y3 * inv);
