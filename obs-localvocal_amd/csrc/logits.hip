@@ -46,14 +46,8 @@ struct SlabRec {                // one per (row, slab); written field group by f
 static_assert(sizeof(SlabRec) == 64, "slab record layout");
 constexpr int REC_FLOATS = MAX_ROWS * PG * (int)(sizeof(SlabRec) / sizeof(float));
 
-__device__ __forceinline__ float wave_max(float v) {
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
-}
-__device__ __forceinline__ float wave_sum(float v) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
+__device__ __forceinline__ float wave_max(float v) { return wave_max_desc(v); }  // (common.hpp: no LDS shuffles, same order)
+__device__ __forceinline__ float wave_sum(float v) { return wave_sum_desc(v); }
 __device__ __forceinline__ double wave_sum_d(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
