@@ -786,14 +786,20 @@ template <int NB, typename OT, bool DESC>
 __device__ __forceinline__ void cross_attn_lean(const float *q, const bf16_t *kc, const bf16_t *vc, const StepGroup *groups, long k_off,
                                                 long v_off, float *part, OT *out, unsigned *head_cnt, int n, int H, int d, int n_ctx,
                                                 int splits, float *lds) {
-    bf16_t *qb = reinterpret_cast<bf16_t *>(lds);  // [16][72]    q rows
-    bf16_t *kt = qb + 16 * 72;                     // [XK][XKD]   K rows
-    bf16_t *vt = kt + XK * XKD;                    // [64][XVLD]  V transposed: [dim][key] (the region keeps 64 rows of XLDP)
-    bf16_t *pb = vt + 64 * XLDP;                   // [16][XLDP]  probabilities
-    float *sc = reinterpret_cast<float *>(pb + 16 * XLDP);  // [NB][XK] scores
-    float *red = sc + NB * XK;                     // [8][64][4]
-    float *ml = red + 8 * 64 * 4;                  // [NB][2]
+    // LDS, under 40 KB for NB <= 5 so that FOUR workgroups share a CU (53 KB and three before): the q and probability tiles
+    // hold their NB real rows only — the MFMA A operand reads 16, and rows beyond NB run on into the tile behind (K, V: any
+    // bytes will do, they feed result rows nobody reads) — and the PV partial sums reuse the K tile, dead since the scores.
+    bf16_t *qb = reinterpret_cast<bf16_t *>(lds);  // [NB][72]    q rows (+ 16 - NB rows of whatever follows)
+    bf16_t *kt = qb + NB * 72;                     // [XK][XKD]   K rows
+    bf16_t *pb = kt + XK * XKD;                    // [NB][XLDP]  probabilities (+ 16 - NB rows of whatever follows)
+    bf16_t *vt = pb + NB * XLDP;                   // [64][XVLD]  V transposed: [dim][key]
+    float *sc = reinterpret_cast<float *>(vt + 64 * XVLD);  // [NB][XK] scores
+    float *ml = sc + NB * XK;                      // [NB][2]
     unsigned *flag = reinterpret_cast<unsigned *>(ml + NB * 2);
+    float *red = reinterpret_cast<float *>(kt);    // [8][64][4]  PV partial sums, written behind the softmax barrier
+    static_assert(8 * 64 * 4 * 4 <= XK * XKD * 2, "the partial sums fit the K tile");
+    static_assert((16 - NB) * 72 <= XK * XKD && (16 - NB) * XLDP <= 64 * XVLD, "operand rows beyond NB stay inside the next tile");
+    static_assert((NB * 72 * 2) % 16 == 0 && (NB * XLDP * 2) % 16 == 0 && (64 * XVLD * 2) % 16 == 0, "16-byte aligned tiles");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
     const int hs = H * splits, g = blockIdx.x / hs, rem = blockIdx.x - g * hs;
     const int h = rem / splits, sp = rem - h * splits;
@@ -950,7 +956,7 @@ template <int NB, typename OT, bool DESC>
 __global__ __launch_bounds__(MT) void cross_attn_lean_kernel(const float *q, const bf16_t *kc, const bf16_t *vc, const StepGroup *groups,
                                                               long k_off, long v_off, float *part, OT *out, unsigned *head_cnt, int n, int H,
                                                               int d, int n_ctx, int splits) {
-    __shared__ __attribute__((aligned(16))) float lds[(16 * 72 + XK * XKD + 64 * XLDP + 16 * XLDP) / 2 + NB * XK + 8 * 64 * 4 + NB * 2 + 16];
+    __shared__ __attribute__((aligned(16))) float lds[(NB * 72 + XK * XKD + NB * XLDP + 64 * XVLD) / 2 + NB * XK + NB * 2 + 16];
     cross_attn_lean<NB, OT, DESC>(q, kc, vc, groups, k_off, v_off, part, out, head_cnt, n, H, d, n_ctx, splits, lds);
 }
 
