@@ -988,6 +988,7 @@ __global__ __launch_bounds__(MT) void cross_touch_kernel(const StepGroup *groups
 // ---- head of a batched step: the StepBlock straight from pinned host memory ----
 // Blocks [0, n_groups * KV_SLOTS): the requests' deferred beam reshuffles of their index tables; the next n_rows blocks
 // embed one token each; the last block copies the StepBlock into device memory for the kernels behind.
+constexpr int STEP_BEGIN_MAX_D = 1280;  // text width the step head's straight-line embedding covers (launch_step_begin_batch checks)
 __global__ __launch_bounds__(256) void step_begin_batch_kernel(const StepBlock *__restrict__ hblk, StepBlock *__restrict__ dblk, int n_rows,
                                                                int n_groups, int n_text_ctx, const bf16_t *__restrict__ te,
                                                                const float *__restrict__ pe, float *__restrict__ x, int d,
@@ -1002,25 +1003,62 @@ __global__ __launch_bounds__(256) void step_begin_batch_kernel(const StepBlock *
         int *new_idx = G->idx_new;
         for (int p = threadIdx.x; p <= n_past; p += 256) new_idx[j * n_text_ctx + p] = p < n_past ? ldg_i32(old_idx + s * n_text_ctx + p) : j;
     } else if (b < n_groups * KV_SLOTS + n_rows) {
+        // Straight-line on purpose: as loops over a run-time d the embedding and the table reads waited for one load per
+        // iteration (five and two dependent round trips behind the two host reads).  Here the row's descriptor is one host
+        // round trip, the embedding loads and the read of the row's group (host again) then travel together, the table reads
+        // follow, and the stores come last.
         const int i = b - n_groups * KV_SLOTS;
-        const long t = hblk->rows[i].token, p = hblk->rows[i].pos;
-        for (int e = threadIdx.x; e < d; e += 256) x[(long)i * d + e] = __uint_as_float((unsigned)te[t * d + e] << 16) + pe[p * d + e];
+        const StepRow *Rw = &hblk->rows[i];
+        const long t = Rw->token, p = Rw->pos;
+        const int sl = Rw->slot, grp = Rw->group;
+        const int *kvi = Rw->kv_idx;
+        constexpr int EI = STEP_BEGIN_MAX_D / 256;
+        unsigned tv[EI];
+        float pv[EI];
+#pragma unroll
+        for (int j = 0; j < EI; ++j) {
+            const int e = min((int)threadIdx.x + 256 * j, d - 1);
+            tv[j] = te[t * d + e];
+            pv[j] = pe[p * d + e];
+        }
         // the row's physical slot per position for the self-attention kernels of every layer (self_attn_lean): what they
         // would read from the row's index table AFTER this kernel's reshuffle blocks — taken from the reshuffle's source
         // where the reshuffle writes (those blocks run beside this one), positions beyond the row's own padded with its last
-        const StepRow *Rw = &hblk->rows[i];
-        const StepGroup *G = &hblk->groups[Rw->group];
-        const int sl = Rw->slot, np = (int)p + 1, src = G->src[sl], rnp = G->reorder_n_past;
+        const StepGroup *G = &hblk->groups[grp];
+        const int np = (int)p + 1, src = G->src[sl], rnp = G->reorder_n_past;
         const bool re = G->reorder_flag != 0 && src >= 0;
-        const int *cur = Rw->kv_idx + (long)sl * n_text_ctx, *old = G->idx_old + (long)(src < 0 ? 0 : src) * n_text_ctx;
-        for (int k = threadIdx.x; k < TILE_TC_MAX; k += 256) {
-            const int pp = min(k, np - 1);
-            phys[(long)i * TILE_TC_MAX + k] = re && pp <= rnp ? (pp < rnp ? ldg_i32(old + pp) : sl) : ldg_i32(cur + pp);
+        const int *cur = kvi + (long)sl * n_text_ctx, *old = G->idx_old + (long)(src < 0 ? 0 : src) * n_text_ctx;
+        constexpr int PI = (TILE_TC_MAX + 255) / 256;
+        int pvv[PI];
+#pragma unroll
+        for (int j = 0; j < PI; ++j) {
+            const int pp = min((int)threadIdx.x + 256 * j, np - 1);
+            const int v = ldg_i32(re && pp < rnp ? old + pp : cur + pp);
+            pvv[j] = re && pp == rnp ? sl : v;
+        }
+#pragma unroll
+        for (int j = 0; j < EI; ++j) {
+            const int e = (int)threadIdx.x + 256 * j;
+            if (e < d) x[(long)i * d + e] = __uint_as_float(tv[j] << 16) + pv[j];
+        }
+#pragma unroll
+        for (int j = 0; j < PI; ++j) {
+            const int k = (int)threadIdx.x + 256 * j;
+            if (k < TILE_TC_MAX) phys[(long)i * TILE_TC_MAX + k] = pvv[j];
         }
     } else {
+        // the whole block in one round trip to host memory: every load is issued before the first store waits for one
         const int *src = reinterpret_cast<const int *>(hblk);
         int *dst = reinterpret_cast<int *>(dblk);
-        for (int k = threadIdx.x; k < (int)(sizeof(StepBlock) / sizeof(int)); k += 256) dst[k] = src[k];
+        constexpr int NI = (int)(sizeof(StepBlock) / sizeof(int)), IT = (NI + 255) / 256;
+        int v[IT];
+#pragma unroll
+        for (int j = 0; j < IT; ++j) v[j] = src[min((int)threadIdx.x + 256 * j, NI - 1)];
+#pragma unroll
+        for (int j = 0; j < IT; ++j) {
+            const int k = (int)threadIdx.x + 256 * j;
+            if (k < NI) dst[k] = v[j];
+        }
     }
 }
 
@@ -1135,8 +1173,8 @@ void launch_proj_batch(const GemvArgs &a, const StepBlock *blk, long kv_layer_of
 void launch_step_begin_batch(const StepBlock *h_block_dev, StepBlock *d_block, int n_rows, int n_groups, int n_text_ctx,
                              const void *tok_emb, const float *pos_emb, float *x, int d, int *row_phys, hipStream_t st) {
     MW_CHECK(h_block_dev && d_block && row_phys && n_rows >= 1 && n_rows <= STEP_MAX_ROWS && n_groups >= 1 && n_groups <= STEP_MAX_GROUPS &&
-                 n_text_ctx <= TILE_TC_MAX,
-             "step_begin_batch: rows / groups");
+                 n_text_ctx <= TILE_TC_MAX && d >= 1 && d <= STEP_BEGIN_MAX_D,
+             "step_begin_batch: rows / groups / width");
     static_assert(sizeof(StepBlock) % sizeof(int) == 0, "StepBlock is copied int by int");
     hipLaunchKernelGGL(step_begin_batch_kernel, dim3(n_groups * KV_SLOTS + n_rows + 1), dim3(256), 0, st, h_block_dev, d_block, n_rows,
                        n_groups, n_text_ctx, (const bf16_t *)tok_emb, pos_emb, x, d, row_phys);
