@@ -88,13 +88,16 @@ __global__ __launch_bounds__(256) void layernorm_mx_kernel(const float *__restri
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float *xr = x + (long)row * ldx;
-    float4 v[NV];
-    float sum = 0.0f;
+    float4 v[NV], wv[NV], bv[NV];  // (weights and biases with the row: loaded in the output loop each slice waited for its own)
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         v[i] = *reinterpret_cast<const float4 *>(xr + (i * 64 + lane) * 4);
-        sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        wv[i] = *reinterpret_cast<const float4 *>(w + (i * 64 + lane) * 4);
+        bv[i] = *reinterpret_cast<const float4 *>(b + (i * 64 + lane) * 4);
     }
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     sum = wave_sum_desc(sum);  // (common.hpp: the shuffle form's partners and order, without its LDS round trips)
     const float mean = sum / (float)d;
     float s2 = 0.0f;
@@ -108,8 +111,7 @@ __global__ __launch_bounds__(256) void layernorm_mx_kernel(const float *__restri
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = (i * 64 + lane) * 4;
-        const float4 ww = *reinterpret_cast<const float4 *>(w + c);
-        const float4 bb = *reinterpret_cast<const float4 *>(b + c);
+        const float4 ww = wv[i], bb = bv[i];
         const float y0 = v[i].x * rstd * ww.x + bb.x, y1 = v[i].y * rstd * ww.y + bb.y, y2 = v[i].z * rstd * ww.z + bb.z,
                     y3 = v[i].w * rstd * ww.w + bb.w;
         if constexpr (WITH_BF16) {
